@@ -1,0 +1,512 @@
+// C ABI of libgato_hip.so (include/gato_hip.h): solver object, stage-level entry points on device
+// pointers, the device-resident whole solve and the host-pointer drop-in for main_call
+// (gpu_library.cu:85-234).
+#include <cstdarg>
+#include <cstdlib>
+#include <vector>
+
+#include "gato_common.h"
+
+namespace gato {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- type-erased op table -------------------------------------------------------------------
+template <typename T, int S, int C>
+static Ops make_ops(int dtype)
+{
+    Ops o;
+    o.S = S; o.C = C; o.dtype = dtype;
+    o.convert = [](const Dims &d, const int *gr, const int *gc, const void *gv, const int *cr, const int *cc,
+                   const void *cv, double rho, void *Gd, void *Cd, hipStream_t st) {
+        return launch_convert<T, S, C>(d, gr, gc, (const T *)gv, cr, cc, (const T *)cv, (T)rho, (T *)Gd, (T *)Cd, st);
+    };
+    o.form_schur = [](const Dims &d, const void *Gd, const void *Cd, const void *g, const void *c, void *Sb,
+                      void *Pb, void *gam, void *Gi, hipStream_t st) {
+        return launch_form_schur<T, S, C>(d, (const T *)Gd, (const T *)Cd, (const T *)g, (const T *)c, (T *)Sb,
+                                          (T *)Pb, (T *)gam, (T *)Gi, st);
+    };
+    o.form_ss = [](const Dims &d, const void *Sb, void *Pb, hipStream_t st) {
+        return launch_form_ss<T, S, C>(d, (const T *)Sb, (T *)Pb, st);
+    };
+    o.compute_dz = [](const Dims &d, const void *Gi, const void *Cd, const void *g, const void *lam, void *dz,
+                      hipStream_t st) {
+        return launch_compute_dz<T, S, C>(d, (const T *)Gi, (const T *)Cd, (const T *)g, (const T *)lam, (T *)dz, st);
+    };
+    o.pcg_plan = [](PcgPlan *p) { return pcg_resident_plan<T, S>(p); };
+    o.pcg_resident = [](const PcgLaunch &a, hipStream_t st) { return launch_pcg_resident<T, S>(a, st); };
+    o.pcg_streaming = [](const Dims &d, const void *Sb, const void *Pb, const void *gam, void *lam, double tol,
+                         int max_iters, int *iters, const PcgStreamWork &w, hipStream_t st) {
+        return launch_pcg_streaming<T, S>(d, (const T *)Sb, (const T *)Pb, (const T *)gam, (T *)lam, (T)tol,
+                                          max_iters, iters, w, st);
+    };
+    return o;
+}
+
+static const std::vector<Ops> &all_ops()
+{
+    static const std::vector<Ops> v = [] {
+        std::vector<Ops> t;
+#define X(S_, C_)                                     \
+    t.push_back(make_ops<float, S_, C_>(GATO_F32));   \
+    t.push_back(make_ops<double, S_, C_>(GATO_F64));
+        GATO_SHAPES(X)
+#undef X
+        return t;
+    }();
+    return v;
+}
+
+const Ops *find_ops(int S, int C, int dtype)
+{
+    for (const Ops &o : all_ops())
+        if (o.S == S && o.C == C && o.dtype == dtype) return &o;
+    return nullptr;
+}
+
+}  // namespace gato
+
+using namespace gato;
+
+// ---- solver object -----------------------------------------------------------------------------
+struct gato_solver {
+    Dims d;
+    int dtype, device;
+    size_t esz;
+    const Ops *ops;
+    int num_cus;
+    // options
+    int pcg_mode, pcg_threads, pcg_groups;
+    // arena
+    char *arena;
+    size_t arena_bytes;
+    void *G_dense, *C_dense, *Ginv, *Sbd, *Pbd, *gamma, *lambda, *dz;
+    int *iters, *status;
+    double *final_eta;
+    unsigned long long *slots;
+    PcgStreamWork sw;
+    PcgPlan plan;
+    // device copies of host CSR inputs for gato_linsys_solve_* (sized on first use)
+    char *in_arena;
+    size_t in_bytes;
+    int last_groups, last_threads, last_mode;
+};
+
+static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+extern "C" const char *gato_last_error(void) { return g_err; }
+extern "C" int gato_version(void) { return 100; }
+
+extern "C" int gato_num_shapes(void)
+{
+    int n = 0;
+#define X(S_, C_) ++n;
+    GATO_SHAPES(X)
+#undef X
+    return n;
+}
+
+extern "C" int gato_shape(int i, int *S, int *C)
+{
+    int n = 0;
+#define X(S_, C_)              \
+    if (n++ == i) {            \
+        *S = S_; *C = C_;      \
+        return GATO_OK;        \
+    }
+    GATO_SHAPES(X)
+#undef X
+    return GATO_EINVAL;
+}
+
+extern "C" int gato_device_info(int device, int *num_cus, int *lds_bytes, char *name, int name_len)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        set_error("no HIP device visible");
+        return GATO_ENODEV;
+    }
+    hipDeviceProp_t p;
+    GATO_HIP_CHECK(hipGetDeviceProperties(&p, device));
+    if (num_cus) *num_cus = p.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int)p.sharedMemPerBlock;
+    if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    return GATO_OK;
+}
+
+extern "C" int gato_infer_shape(const int *C_row, int len_C_row, int len_g, int len_c, int *S, int *C, int *K)
+{
+    // S = number of leading rows of C holding exactly one entry (row-block 0 = identity,
+    // gato_schur.cuh:725); then K = len_c / S and C from N = (S+C)K - C.
+    if (!C_row || len_C_row != len_c + 1 || len_c <= 0 || len_g <= 0) {
+        set_error("infer_shape: len(C_row)=%d must be len(c)+1=%d", len_C_row, len_c + 1);
+        return GATO_EINVAL;
+    }
+    int s = 0;
+    while (s < len_c && C_row[s + 1] - C_row[s] == 1) ++s;
+    if (s == 0 || len_c % s != 0) {
+        // all rows single-entry (K == 1) or no identity block: fall back to the compiled shapes
+        for (int i = 0; i < gato_num_shapes(); ++i) {
+            int ss, cc;
+            gato_shape(i, &ss, &cc);
+            if (len_c % ss == 0) {
+                int k = len_c / ss;
+                if ((long long)(ss + cc) * k - cc == len_g) { *S = ss; *C = cc; *K = k; return GATO_OK; }
+            }
+        }
+        set_error("infer_shape: cannot infer S from C_row (leading identity rows = %d, len(c) = %d)", s, len_c);
+        return GATO_EINVAL;
+    }
+    int k = len_c / s;
+    if (k == 1) {
+        if (len_g != s) { set_error("infer_shape: K=1 needs len(g) == S"); return GATO_EINVAL; }
+        *S = s; *K = 1; *C = 0;
+        for (int i = 0; i < gato_num_shapes(); ++i) { int ss, cc; gato_shape(i, &ss, &cc); if (ss == s) *C = cc; }
+        return GATO_OK;
+    }
+    long long num = (long long)len_g - (long long)s * k;   // = C*(K-1)
+    if (num < 0 || num % (k - 1) != 0) {
+        set_error("infer_shape: len(g)=%d inconsistent with S=%d K=%d", len_g, s, k);
+        return GATO_EINVAL;
+    }
+    *S = s; *K = k; *C = (int)(num / (k - 1));
+    return GATO_OK;
+}
+
+extern "C" int gato_solver_create(int S, int C, int K, int dtype, int device, gato_solver **out)
+{
+    if (!out || K < 1 || (dtype != GATO_F32 && dtype != GATO_F64)) {
+        set_error("solver_create: bad arguments (K=%d dtype=%d)", K, dtype);
+        return GATO_EINVAL;
+    }
+    const Ops *ops = find_ops(S, C, dtype);
+    if (!ops) {
+        set_error("solver_create: (STATE_SIZE=%d, CONTROL_SIZE=%d) is not a compiled shape", S, C);
+        return GATO_ESHAPE;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) {
+        set_error("solver_create: no HIP device %d (visible devices: %d)", device, count);
+        return GATO_ENODEV;
+    }
+    GATO_HIP_CHECK(hipSetDevice(device));
+    gato_solver *s = new gato_solver();
+    memset(s, 0, sizeof(*s));
+    s->d = Dims{S, C, K};
+    s->dtype = dtype;
+    s->device = device;
+    s->esz = dtype == GATO_F32 ? 4 : 8;
+    s->ops = ops;
+    hipDeviceProp_t p;
+    GATO_HIP_CHECK(hipGetDeviceProperties(&p, device));
+    s->num_cus = p.multiProcessorCount;
+    ops->pcg_plan(&s->plan);
+    s->pcg_mode = GATO_PCG_AUTO;
+
+    const Dims &d = s->d;
+    const size_t e = s->esz;
+    const int max_groups = 4096;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 8); return o; };
+    // slots first: they are memset before every launch (keep them at the allocation start)
+    const size_t o_slots = take((size_t)2 * 256 * pcg_slot_granules(S, (int)e) * 8);
+    const size_t o_status = take(64);
+    const size_t o_G = take(d.g_dense() * e), o_C = take(d.c_dense() * e), o_Gi = take(d.g_dense() * e);
+    const size_t o_S = take(d.bd() * e), o_P = take(d.bd() * e), o_gam = take(d.sk() * e);
+    const size_t o_lam = take(d.sk() * e), o_dz = take(d.N() * e);
+    const size_t o_vec = take(6 * d.sk() * e);
+    const size_t o_part = take((size_t)4 * max_groups * e), o_scal = take(64 * 8), o_done = take(64);
+    s->arena_bytes = off;
+    GATO_HIP_CHECK(hipMalloc((void **)&s->arena, off));
+    GATO_HIP_CHECK(hipMemset(s->arena, 0, off));
+    char *a = s->arena;
+    s->slots = (unsigned long long *)(a + o_slots);
+    s->status = (int *)(a + o_status);
+    s->iters = (int *)(a + o_status + 8);
+    s->final_eta = (double *)(a + o_status + 16);
+    s->G_dense = a + o_G; s->C_dense = a + o_C; s->Ginv = a + o_Gi;
+    s->Sbd = a + o_S; s->Pbd = a + o_P; s->gamma = a + o_gam; s->lambda = a + o_lam; s->dz = a + o_dz;
+    s->sw.vecs = a + o_vec;
+    s->sw.partials = a + o_part; s->sw.scalars = a + o_scal; s->sw.done = (int *)(a + o_done);
+    s->sw.max_groups = max_groups;
+    *out = s;
+    return GATO_OK;
+}
+
+extern "C" int gato_solver_destroy(gato_solver *s)
+{
+    if (!s) return GATO_OK;
+    hipSetDevice(s->device);
+    if (s->arena) hipFree(s->arena);
+    if (s->in_arena) hipFree(s->in_arena);
+    delete s;
+    return GATO_OK;
+}
+
+extern "C" void *gato_solver_buffer(gato_solver *s, int which)
+{
+    switch (which) {
+        case 0: return s->G_dense;
+        case 1: return s->C_dense;
+        case 2: return s->Ginv;
+        case 3: return s->Sbd;
+        case 4: return s->Pbd;
+        case 5: return s->gamma;
+        case 6: return s->lambda;
+        case 7: return s->dz;
+        case 8: return s->iters;
+        default: return nullptr;
+    }
+}
+
+extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int value)
+{
+    if (!strcmp(name, "pcg_mode")) s->pcg_mode = value;
+    else if (!strcmp(name, "pcg_threads")) s->pcg_threads = value;
+    else if (!strcmp(name, "pcg_groups")) s->pcg_groups = value;
+    else { set_error("unknown option %s", name); return GATO_EINVAL; }
+    return GATO_OK;
+}
+
+extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *value)
+{
+    if (!strcmp(name, "pcg_mode")) *value = s->pcg_mode;
+    else if (!strcmp(name, "pcg_threads")) *value = s->pcg_threads;
+    else if (!strcmp(name, "pcg_groups")) *value = s->pcg_groups;
+    else if (!strcmp(name, "last_groups")) *value = s->last_groups;
+    else if (!strcmp(name, "last_threads")) *value = s->last_threads;
+    else if (!strcmp(name, "last_mode")) *value = s->last_mode;
+    else if (!strcmp(name, "num_cus")) *value = s->num_cus;
+    else if (!strcmp(name, "max_resident_knots")) *value = s->plan.max_knots_per_wg * (s->num_cus < 256 ? s->num_cus : 256);
+    else { set_error("unknown option %s", name); return GATO_EINVAL; }
+    return GATO_OK;
+}
+
+// ---- stage-level entry points -------------------------------------------------------------------
+extern "C" int gato_convert(gato_solver *s, const int *d_G_row, const int *d_G_col, const void *d_G_val,
+                            const int *d_C_row, const int *d_C_col, const void *d_C_val, double rho,
+                            void *d_G_dense, void *d_C_dense, void *stream)
+{
+    return s->ops->convert(s->d, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, rho, d_G_dense, d_C_dense,
+                           (hipStream_t)stream);
+}
+
+extern "C" int gato_form_schur(gato_solver *s, const void *d_G_dense, const void *d_C_dense, const void *d_g,
+                               const void *d_c, void *d_S, void *d_Pinv, void *d_gamma, void *d_Ginv_dense,
+                               void *stream)
+{
+    return s->ops->form_schur(s->d, d_G_dense, d_C_dense, d_g, d_c, d_S, d_Pinv, d_gamma, d_Ginv_dense,
+                              (hipStream_t)stream);
+}
+
+extern "C" int gato_form_ss(gato_solver *s, const void *d_S, void *d_Pinv, void *stream)
+{
+    return s->ops->form_ss(s->d, d_S, d_Pinv, (hipStream_t)stream);
+}
+
+// Geometry of the resident launch.  One workgroup per CU at most (all workgroups must be
+// co-resident: they hand partial dots and halo blocks to each other inside the launch).
+static int plan_resident(gato_solver *s, int *groups, int *threads, int *kpw)
+{
+    const int S = s->d.S, K = s->d.K;
+    const int max_wg = s->num_cus < 256 ? s->num_cus : 256;
+    int t = s->pcg_threads;
+    int g = s->pcg_groups;
+    const int maxT = s->plan.max_threads;
+    if (t > 0) {
+        t = (t + 63) / 64 * 64;
+        if (t > maxT) t = maxT;
+        if (t < 64) t = 64;
+    }
+    if (g > 0 && t == 0) {
+        int k_per = (K + g - 1) / g;
+        t = (k_per * S + 63) / 64 * 64;
+        if (t < 64) t = 64;
+        if (t > maxT) return 0;
+    }
+    if (t == 0) {
+        // auto: one workgroup while the problem fits one CU's registers (no inter-CU traffic);
+        // otherwise the fewest waves per SIMD that still fits the chip.
+        if (K * S <= maxT) t = (K * S + 63) / 64 * 64;
+        else {
+            t = 256;
+            while (t < maxT && (long long)((K + (t / S) - 1) / (t / S)) > max_wg) t *= 2;
+            if (t > maxT) t = maxT;
+        }
+        if (t < 64) t = 64;
+    }
+    int k_per_max = t / S;
+    if (k_per_max < 1) return 0;
+    int W = (K + k_per_max - 1) / k_per_max;
+    if (g > 0 && g >= W) W = g;
+    if (W > max_wg) return 0;
+    int k_per = (K + W - 1) / W;                     // balanced
+    W = (K + k_per - 1) / k_per;
+    *groups = W; *threads = t; *kpw = k_per;
+    return 1;
+}
+
+extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
+                        double exit_tol, int max_iters, int *d_iters, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    int groups = 0, threads = 0, kpw = 0;
+    int mode = s->pcg_mode;
+    const bool fits = plan_resident(s, &groups, &threads, &kpw) != 0;
+    if (mode == GATO_PCG_AUTO) mode = fits ? GATO_PCG_RESIDENT : GATO_PCG_STREAMING;
+    if (mode == GATO_PCG_RESIDENT) {
+        if (!fits) {
+            set_error("pcg: K=%d does not fit the resident kernel on %d CUs (threads=%d groups=%d)", s->d.K,
+                      s->num_cus, s->pcg_threads, s->pcg_groups);
+            return GATO_EINVAL;
+        }
+        PcgLaunch a;
+        a.S_bd = d_S; a.P_bd = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda;
+        a.K = s->d.K; a.max_iters = max_iters; a.exit_tol = exit_tol;
+        a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
+        a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
+        a.final_eta = s->final_eta;
+        a.timeout_ticks = 200000000ull;   // 2 s at 100 MHz
+        s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT;
+        return s->ops->pcg_resident(a, st);
+    }
+    s->last_mode = GATO_PCG_STREAMING; s->last_groups = 0; s->last_threads = 0;
+    return s->ops->pcg_streaming(s->d, d_S, d_Pinv, d_gamma, d_lambda, exit_tol, max_iters,
+                                 d_iters ? d_iters : s->iters, s->sw, st);
+}
+
+extern "C" int gato_pcg_status(gato_solver *s, int *status)
+{
+    int v = 0;
+    GATO_HIP_CHECK(hipMemcpy(&v, s->status, sizeof(int), hipMemcpyDeviceToHost));
+    if (status) *status = v;
+    if (v != 0) { set_error("pcg: in-kernel hand-off timed out"); return GATO_ETIMEOUT; }
+    return GATO_OK;
+}
+
+extern "C" int gato_compute_dz(gato_solver *s, const void *d_Ginv_dense, const void *d_C_dense, const void *d_g,
+                               const void *d_lambda, void *d_dz, void *stream)
+{
+    return s->ops->compute_dz(s->d, d_Ginv_dense, d_C_dense, d_g, d_lambda, d_dz, (hipStream_t)stream);
+}
+
+extern "C" int gato_linsys_device(gato_solver *s, const int *d_G_row, const int *d_G_col, const void *d_G_val,
+                                  const int *d_C_row, const int *d_C_col, const void *d_C_val, const void *d_g,
+                                  const void *d_c, double exit_tol, int max_iters, double rho, void *d_lambda,
+                                  void *d_dz, void *stream)
+{
+    int rc;
+    void *lam = d_lambda ? d_lambda : s->lambda;
+    void *dz = d_dz ? d_dz : s->dz;
+    if ((rc = gato_convert(s, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, rho, s->G_dense, s->C_dense, stream))) return rc;
+    if ((rc = gato_form_schur(s, s->G_dense, s->C_dense, d_g, d_c, s->Sbd, s->Pbd, s->gamma, s->Ginv, stream))) return rc;
+    if ((rc = gato_form_ss(s, s->Sbd, s->Pbd, stream))) return rc;
+    if ((rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream))) return rc;
+    if ((rc = gato_compute_dz(s, s->Ginv, s->C_dense, d_g, lam, dz, stream))) return rc;
+    return GATO_OK;
+}
+
+// ---- host-pointer drop-in for main_call (gpu_library.cu:85-234) -----------------------------------
+template <typename T>
+static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const int *G_col, const T *G_val, int nnz_G,
+                             const int *C_row, int len_C_row, const int *C_col, const T *C_val, int nnz_C,
+                             const T *g, int len_g, const T *c, int len_c, const T *lambda_in, int S, int C, int K,
+                             int testiters, T exit_tol, int max_iters, int warm_start, T rho, T *lambda_out,
+                             T *dz_out, int *iters_out, float *ms_out)
+{
+    (void)lambda_in; (void)warm_start;   // D5: the reference resets lambda to 0 (gato_pcg.cuh:303)
+    const long long N = (long long)(S + C) * K - C;
+    if (len_G_row != N + 1 || len_C_row != (long long)S * K + 1 || len_g != N || len_c != S * K ||
+        nnz_G < 0 || nnz_C < 0 || testiters < 1) {
+        set_error("linsys_solve: lengths do not match S=%d C=%d K=%d: len(G_row)=%d (want %lld), len(C_row)=%d "
+                  "(want %d), len(g)=%d (want %lld), len(c)=%d (want %d)",
+                  S, C, K, len_G_row, N + 1, len_C_row, S * K + 1, len_g, N, len_c, S * K);
+        return GATO_EINVAL;
+    }
+    if (G_row[len_G_row - 1] != nnz_G || C_row[len_C_row - 1] != nnz_C) {
+        set_error("linsys_solve: indptr[-1] does not match nnz (G %d vs %d, C %d vs %d)", G_row[len_G_row - 1], nnz_G,
+                  C_row[len_C_row - 1], nnz_C);
+        return GATO_EINVAL;
+    }
+    gato_solver *s = nullptr;
+    int rc = gato_solver_create(S, C, K, dtype, 0, &s);
+    if (rc) return rc;
+    const char *env = getenv("GATO_PCG_MODE");
+    if (env) s->pcg_mode = atoi(env);
+
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off += align_up(b ? b : 8); return o; };
+    const size_t oGr = take(sizeof(int) * len_G_row), oGc = take(sizeof(int) * nnz_G), oGv = take(sizeof(T) * nnz_G);
+    const size_t oCr = take(sizeof(int) * len_C_row), oCc = take(sizeof(int) * nnz_C), oCv = take(sizeof(T) * nnz_C);
+    const size_t og = take(sizeof(T) * len_g), oc = take(sizeof(T) * len_c);
+    hipError_t e = hipMalloc((void **)&s->in_arena, off);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(e)); gato_solver_destroy(s); return GATO_EHIP; }
+    char *a = s->in_arena;
+    hipStream_t st = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    auto fail = [&](int code) { if (ev0) hipEventDestroy(ev0); if (ev1) hipEventDestroy(ev1); gato_solver_destroy(s); return code; };
+#define CP(dst, src, bytes) \
+    if ((bytes) && (e = hipMemcpyAsync(a + dst, src, bytes, hipMemcpyHostToDevice, st)) != hipSuccess) { \
+        set_error("H2D copy failed: %s", hipGetErrorString(e)); return fail(GATO_EHIP); }
+    CP(oGr, G_row, sizeof(int) * len_G_row) CP(oGc, G_col, sizeof(int) * nnz_G) CP(oGv, G_val, sizeof(T) * nnz_G)
+    CP(oCr, C_row, sizeof(int) * len_C_row) CP(oCc, C_col, sizeof(int) * nnz_C) CP(oCv, C_val, sizeof(T) * nnz_C)
+    CP(og, g, sizeof(T) * len_g) CP(oc, c, sizeof(T) * len_c)
+#undef CP
+    hipEventCreate(&ev0);
+    hipEventCreate(&ev1);
+    int iters = 0;
+    for (int i = 0; i < testiters; ++i) {                       // gpu_library.cu:169-192
+        hipEventRecord(ev0, st);
+        rc = gato_linsys_device(s, (const int *)(a + oGr), (const int *)(a + oGc), a + oGv, (const int *)(a + oCr),
+                                (const int *)(a + oCc), a + oCv, a + og, a + oc, (double)exit_tol, max_iters,
+                                (double)rho, nullptr, nullptr, st);
+        if (rc) return fail(rc);
+        if ((e = hipMemcpyAsync(lambda_out, s->lambda, sizeof(T) * (size_t)S * K, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+            (e = hipMemcpyAsync(dz_out, s->dz, sizeof(T) * (size_t)N, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+            (e = hipMemcpyAsync(&iters, s->iters, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) {
+            set_error("D2H copy failed: %s", hipGetErrorString(e));
+            return fail(GATO_EHIP);
+        }
+        hipEventRecord(ev1, st);
+        if ((e = hipEventSynchronize(ev1)) != hipSuccess) {
+            set_error("solve failed: %s", hipGetErrorString(e));
+            return fail(GATO_EHIP);
+        }
+        float ms = 0;
+        hipEventElapsedTime(&ms, ev0, ev1);
+        if (ms_out) ms_out[i] = ms;
+        if (i == 0 && iters_out) *iters_out = iters;            // the reference prints the first run's count (:189-191)
+        if ((rc = gato_pcg_status(s, nullptr))) return fail(rc);
+    }
+    return fail(GATO_OK);
+}
+
+extern "C" int gato_linsys_solve_f32(const int *G_row, int len_G_row, const int *G_col, const float *G_val, int nnz_G,
+                                     const int *C_row, int len_C_row, const int *C_col, const float *C_val, int nnz_C,
+                                     const float *g, int len_g, const float *c, int len_c, const float *lambda_in,
+                                     int S, int C, int K, int testiters, float exit_tol, int max_iters, int warm_start,
+                                     float rho, float *lambda_out, float *dz_out, int *iters_out, float *ms_out)
+{
+    return linsys_solve_host<float>(GATO_F32, G_row, len_G_row, G_col, G_val, nnz_G, C_row, len_C_row, C_col, C_val,
+                                    nnz_C, g, len_g, c, len_c, lambda_in, S, C, K, testiters, exit_tol, max_iters,
+                                    warm_start, rho, lambda_out, dz_out, iters_out, ms_out);
+}
+
+extern "C" int gato_linsys_solve_f64(const int *G_row, int len_G_row, const int *G_col, const double *G_val, int nnz_G,
+                                     const int *C_row, int len_C_row, const int *C_col, const double *C_val, int nnz_C,
+                                     const double *g, int len_g, const double *c, int len_c, const double *lambda_in,
+                                     int S, int C, int K, int testiters, double exit_tol, int max_iters, int warm_start,
+                                     double rho, double *lambda_out, double *dz_out, int *iters_out, float *ms_out)
+{
+    return linsys_solve_host<double>(GATO_F64, G_row, len_G_row, G_col, G_val, nnz_G, C_row, len_C_row, C_col, C_val,
+                                     nnz_C, g, len_g, c, len_c, lambda_in, S, C, K, testiters, exit_tol, max_iters,
+                                     warm_start, rho, lambda_out, dz_out, iters_out, ms_out);
+}

@@ -1,0 +1,122 @@
+// Internal header of libgato_hip.so (gfx950 only).  Not part of the C ABI (include/gato_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/gato_hip.h"
+
+// (S, C) instantiations compiled in.  The reference is compiled for exactly one triple
+// (CMakeLists.txt:18); here K is a runtime value and (S, C) picks one of these.
+#define GATO_SHAPES(X) X(2, 1) X(14, 7) X(32, 16)
+
+namespace gato {
+
+void set_error(const char *fmt, ...);
+
+// fused multiply-add in the operand type (__builtin_fma alone would promote floats to double)
+__device__ __forceinline__ float fmaT(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fmaT(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+#define GATO_HIP_CHECK(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            ::gato::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                              __LINE__);                                                      \
+            return GATO_EHIP;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+// Device layout sizes in elements (gato_defines.h:32-37, gpu_library.cu:40-45).
+struct Dims {
+    int S, C, K;
+    __host__ __device__ int n() const { return S + C; }
+    __host__ __device__ size_t N() const { return (size_t)(S + C) * K - C; }
+    __host__ __device__ size_t g_dense() const { return (size_t)(S * S + C * C) * K - C * C; }
+    __host__ __device__ size_t c_dense() const { return (size_t)(S * S + S * C) * (K > 0 ? K - 1 : 0); }
+    __host__ __device__ size_t bd() const { return (size_t)3 * S * S * K; }
+    __host__ __device__ size_t sk() const { return (size_t)S * K; }
+};
+
+// ---- persistent (resident) PCG launch description ------------------------------------------
+struct PcgLaunch {
+    const void *S_bd, *P_bd, *gamma;
+    void *lambda;
+    int K;
+    int max_iters;
+    double exit_tol;
+    int knots_per_wg;            // contiguous knots owned by each workgroup (last may own fewer)
+    int groups;                  // W = gridDim.x
+    int threads;                 // blockDim.x (multiple of 64, >= knots_per_wg * S)
+    unsigned long long *slots;   // hand-off granules, zeroed before every launch
+    int *iters;                  // device
+    int *status;                 // device, 0 ok / 1 timeout
+    double *final_eta;           // device (optional)
+    unsigned long long timeout_ticks;  // s_memrealtime ticks (100 MHz)
+};
+
+// Granules (8 B: {epoch:32 | payload:32}) per workgroup and parity in the hand-off area.
+// Line 0 (16 granules) holds the partial dot, then first-block and last-block halos.
+__host__ __device__ inline int pcg_slot_granules(int S, int esz)
+{
+    int gpv = esz / 4;                       // granules per value
+    int halo = 2 * S * gpv;
+    return 16 + ((halo + 15) / 16) * 16;
+}
+
+struct PcgPlan {
+    int max_threads;     // launch bound of the instantiation
+    int max_knots_per_wg;
+};
+
+// Per-(dtype, S, C) kernel launchers, defined in the .hip files and instantiated for GATO_SHAPES.
+template <typename T, int S, int C>
+int launch_convert(const Dims &d, const int *G_row, const int *G_col, const T *G_val, const int *C_row,
+                   const int *C_col, const T *C_val, T rho, T *Gd, T *Cd, hipStream_t st);
+template <typename T, int S, int C>
+int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const T *c, T *Sbd, T *Pbd,
+                      T *gamma, T *Ginv, hipStream_t st);
+template <typename T, int S, int C>
+int launch_form_ss(const Dims &d, const T *Sbd, T *Pbd, hipStream_t st);
+template <typename T, int S, int C>
+int launch_compute_dz(const Dims &d, const T *Ginv, const T *Cd, const T *g, const T *lambda, T *dz,
+                      hipStream_t st);
+template <typename T, int S>
+int pcg_resident_plan(PcgPlan *plan);
+template <typename T, int S>
+int launch_pcg_resident(const PcgLaunch &a, hipStream_t st);
+
+// Streaming PCG (two launches per iteration), gato_pcg_stream.hip
+struct PcgStreamWork {
+    void *vecs;                    // 6 consecutive S*K vectors: r[2], p[2], upsilon, r~
+    void *partials;                // [4][max_groups] of T: eta' ring of 3 + v
+    void *scalars;                 // final eta (double)
+    int *done;                     // device flag
+    int max_groups;
+};
+template <typename T, int S>
+int launch_pcg_streaming(const Dims &d, const T *Sbd, const T *Pbd, const T *gamma, T *lambda,
+                         T exit_tol, int max_iters, int *iters, const PcgStreamWork &w, hipStream_t st);
+
+// Type-erased table used by the C ABI.
+struct Ops {
+    int S, C, dtype;
+    int (*convert)(const Dims &, const int *, const int *, const void *, const int *, const int *,
+                   const void *, double, void *, void *, hipStream_t);
+    int (*form_schur)(const Dims &, const void *, const void *, const void *, const void *, void *, void *,
+                      void *, void *, hipStream_t);
+    int (*form_ss)(const Dims &, const void *, void *, hipStream_t);
+    int (*compute_dz)(const Dims &, const void *, const void *, const void *, const void *, void *,
+                      hipStream_t);
+    int (*pcg_plan)(PcgPlan *);
+    int (*pcg_resident)(const PcgLaunch &, hipStream_t);
+    int (*pcg_streaming)(const Dims &, const void *, const void *, const void *, void *, double, int, int *,
+                         const PcgStreamWork &, hipStream_t);
+};
+const Ops *find_ops(int S, int C, int dtype);
+
+}  // namespace gato

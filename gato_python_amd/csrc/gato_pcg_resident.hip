@@ -1,0 +1,357 @@
+// Resident PCG for gfx950: the whole preconditioned-CG solve on the block-tridiagonal Schur
+// system in ONE persistent launch, matrices register-resident.
+//
+// Replaces parallelPCG / parallelPCG_inner (src/gato_pcg.cuh:270-470) and its helpers
+// loadBlockTriDiagonal_offDiagonal / matVecMultBlockTriDiagonal (src/gato_utils.cuh:121-185),
+// dotProd / reducePlus (:253-287) and the atomicAdd + grid.sync() reductions (gato_pcg.cuh:331-393).
+//
+// MI355X design (not the reference's one-block-of-S-threads-per-knot):
+//  * lane = one row of one knot; the lane keeps its 3S entries of S and 3S entries of Pinv in
+//    VGPRs for the whole solve (84 VGPRs fp32 / 168 fp64 at S=14) - the 128 MB register file of
+//    the chip holds every BASELINE shape, so the hot loop touches no HBM at all.
+//  * a workgroup owns a contiguous range of knots; the 3S-wide operand window [x_{k-1};x_k;x_{k+1}]
+//    is read from LDS with 16-byte broadcast reads (knot stride padded to 16 B multiples).
+//  * dots: in-lane product -> wave64 butterfly -> per-wave LDS partial -> fixed-order sum.
+//    Deterministic, no float atomics (the reference's atomicAdd order is unspecified).
+//  * one workgroup (K=50 fp32: 11 waves on one CU): no inter-workgroup traffic at all, six
+//    s_barriers per iteration.
+//  * several workgroups: two hand-offs per iteration (the algorithmic minimum for PCG).  Each
+//    workgroup publishes [partial dot | first S-block | last S-block] of the vector it just
+//    produced as 8-byte {epoch,payload} granules (write-through agent-scope stores), wave 0 of
+//    every workgroup sweeps the W partials and its two neighbours' blocks until every tag equals
+//    the epoch (MI355X guide: "R2: the data IS the flag").  Ghost blocks of r and p are then
+//    advanced locally (ghost_r -= alpha*ghost_upsilon, ghost_p = ghost_rtilde + beta*ghost_p), so
+//    the reference's four grid.sync() per iteration become two all-gathers and no barrier.
+//    Granules are double-buffered by epoch parity; every spin is bounded.
+#include "gato_common.h"
+
+namespace gato {
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) int gi32;
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { typedef float __attribute__((ext_vector_type(4))) type; static constexpr int W = 4; };
+template <> struct VecOf<double> { typedef double __attribute__((ext_vector_type(2))) type; static constexpr int W = 2; };
+
+__device__ __forceinline__ unsigned f2u(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float u2f(unsigned x) { return __uint_as_float(x); }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---- granule transport -------------------------------------------------------------------
+template <typename T> struct Granule;
+template <> struct Granule<float> {
+    static constexpr int GPV = 1;
+    __device__ static __forceinline__ void store(gu64 *g, unsigned ep, float v)
+    {
+        __hip_atomic_store(g, ((unsigned long long)ep << 32) | f2u(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // returns true when the tag matches; value in v
+    __device__ static __forceinline__ bool load(gu64 *g, unsigned ep, float &v)
+    {
+        unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = u2f((unsigned)x);
+        return (unsigned)(x >> 32) == ep;
+    }
+};
+template <> struct Granule<double> {
+    static constexpr int GPV = 2;
+    __device__ static __forceinline__ void store(gu64 *g, unsigned ep, double v)
+    {
+        unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        __hip_atomic_store(g, ((unsigned long long)ep << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 1, ((unsigned long long)ep << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ static __forceinline__ bool load(gu64 *g, unsigned ep, double &v)
+    {
+        unsigned long long lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+        return (unsigned)(lo >> 32) == ep && (unsigned)(hi >> 32) == ep;
+    }
+};
+
+constexpr int pad_to(int x, int m) { return (x + m - 1) / m * m; }
+
+template <typename T, int S, int MAXT>
+struct ResidentCfg {
+    static constexpr int VW = VecOf<T>::W;
+    static constexpr int SP = pad_to(S, VW);           // padded knot stride in LDS (16-B multiple)
+    static constexpr int MAXK = (MAXT + S - 1) / S;    // local knots incl. the partly filled one
+    static constexpr int NV = SP / VW;
+    static constexpr int MAXW = 256;                   // workgroups (one per CU)
+    static constexpr int PM = MAXW / 64;               // partial granule loads per lane
+};
+
+// y_row = [L M R]_row . window  - window read from LDS with 16-byte broadcast reads.
+template <typename T, int S, int SP>
+__device__ __forceinline__ T row_times_window(const T (&m)[3 * S], const T *xw)
+{
+    typedef typename VecOf<T>::type V;
+    constexpr int VW = VecOf<T>::W;
+    constexpr int NV = SP / VW;
+    T acc = (T)0;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            V v = *reinterpret_cast<const V *>(xw + b * SP + i * VW);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                if (i * VW + e < S) acc = gato::fmaT(m[b * S + i * VW + e], v[e], acc);
+            }
+        }
+    }
+    return acc;
+}
+
+template <typename T, int S, int MAXT>
+__global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
+{
+    typedef ResidentCfg<T, S, MAXT> Cfg;
+    typedef Granule<T> Gr;
+    constexpr int SP = Cfg::SP;
+    constexpr int GPV = Gr::GPV;
+
+    __shared__ __attribute__((aligned(16))) T xs[2][(Cfg::MAXK + 2) * SP];   // [0] = p window, [1] = r window
+    __shared__ T wpart[MAXT / 64];
+    __shared__ T gh[2][32];          // ghost blocks of the vector just gathered: [0] left, [1] right
+    __shared__ T bc[2];              // broadcast scalars
+    __shared__ int s_abort;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int W = gridDim.x;
+    const int wg = blockIdx.x;
+    const int K = a.K;
+    const int k0 = wg * a.knots_per_wg;
+    const int nk = min(a.knots_per_wg, K - k0);
+    const int j = tid / S;                 // local knot
+    const int r_ = tid - j * S;            // row inside the knot
+    const bool active = j < nk;
+    const int k = k0 + j;
+    const bool has_left = k0 > 0;
+    const bool has_right = k0 + nk < K;
+
+    const T *__restrict__ dS = static_cast<const T *>(a.S_bd);
+    const T *__restrict__ dP = static_cast<const T *>(a.P_bd);
+    const T *__restrict__ dG = static_cast<const T *>(a.gamma);
+    T *__restrict__ dL = static_cast<T *>(a.lambda);
+
+    // ---- load this lane's rows of S and Pinv into registers (once per solve) ----------------
+    // bd layout: block-row k = [left|main|right], each S*S column-major -> element (r, c) of the
+    // S x 3S strip sits at c*S + r (gato_utils.cuh:53-54,97-98).  First/last block rows have no
+    // left/right block (gato_utils.cuh:157-174): those entries are forced to zero here.
+    T sm[3 * S], pm[3 * S];
+    {
+        const size_t base = (size_t)(active ? k : 0) * 3 * S * S + r_;
+#pragma unroll
+        for (int c = 0; c < 3 * S; ++c) {
+            const bool ok = active && !(k == 0 && c < S) && !(k == K - 1 && c >= 2 * S);
+            sm[c] = ok ? dS[base + (size_t)c * S] : (T)0;
+            pm[c] = ok ? dP[base + (size_t)c * S] : (T)0;
+        }
+    }
+
+    // ---- hand-off area ----------------------------------------------------------------------
+    const int slotG = pcg_slot_granules(S, (int)sizeof(T));
+    gu64 *slots = (gu64 *)a.slots;
+    gi32 *g_status = (gi32 *)a.status;
+    const unsigned long long t_limit = a.timeout_ticks;
+
+    if (tid == 0) s_abort = 0;
+    for (int i = tid; i < 2 * (Cfg::MAXK + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = (T)0;
+    __syncthreads();
+
+    // r = gamma, lambda = 0 (gato_pcg.cuh:300-304); ghost r read straight from gamma.
+    T lam = (T)0;
+    T r = active ? dG[(size_t)k * S + r_] : (T)0;
+    T p = (T)0, ups, rt;
+    if (active) xs[1][(j + 1) * SP + r_] = r;
+    if (tid < S) {
+        if (has_left) xs[1][tid] = dG[(size_t)(k0 - 1) * S + tid];
+    } else if (tid < 2 * S) {
+        if (has_right) xs[1][(nk + 1) * SP + (tid - S)] = dG[(size_t)(k0 + nk) * S + (tid - S)];
+    }
+    __syncthreads();
+
+    unsigned epoch = 0;
+    T eta = (T)0, eta_new = (T)0;
+    int iters = a.max_iters;
+    const T tol = (T)a.exit_tol;
+    bool aborted = false;
+
+    // One reduction + halo exchange.  `val` = the vector just produced (upsilon or r~), `prod` the
+    // lane's dot contribution.  On return: total in every thread; gh[][] = neighbours' boundary
+    // blocks of `val` (zeros where there is no neighbour).
+    auto allreduce_and_halo = [&](T val, T prod, T &total) {
+        ++epoch;
+        const T ws = wave_sum(prod);
+        if (lane == 0) wpart[wave] = ws;
+        gu64 *mine = slots + ((size_t)(epoch & 1) * W + wg) * slotG;
+        if (W > 1 && active) {
+            if (j == 0) Gr::store(mine + 16 + r_ * GPV, epoch, val);
+            if (j == nk - 1) Gr::store(mine + 16 + (S + r_) * GPV, epoch, val);
+        }
+        __syncthreads();                                                       // B1
+        if (wave == 0) {
+            T tot = (T)0;
+            for (int w = 0; w < nwaves; ++w) tot += wpart[w];
+            if (W > 1) {
+                if (lane == 0) Gr::store(mine, epoch, tot);
+                // sweep: partials of all workgroups + neighbours' halo blocks
+                T pv[Cfg::PM];
+                T hv = (T)0;
+                gu64 *pbase = slots + (size_t)(epoch & 1) * W * slotG;
+                const bool want_l = has_left && lane < S;
+                const bool want_r = has_right && lane >= 32 && lane < 32 + S;
+                gu64 *hptr = want_l ? pbase + (size_t)(wg - 1) * slotG + 16 + (S + lane) * GPV
+                                    : pbase + (size_t)(wg + 1) * slotG + 16 + (lane - 32) * GPV;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                bool fail = false;
+                for (unsigned spin = 0;; ++spin) {
+                    bool ok = true;
+#pragma unroll
+                    for (int m = 0; m < Cfg::PM; ++m) {
+                        const int q = lane + 64 * m;
+                        pv[m] = (T)0;
+                        if (q < W) ok &= Gr::load(pbase + (size_t)q * slotG, epoch, pv[m]);
+                    }
+                    if (want_l || want_r) ok &= Gr::load(hptr, epoch, hv);
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((spin & 255u) == 255u) {
+                        const bool late = __builtin_amdgcn_s_memrealtime() - t0 > t_limit;
+                        const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                        if (late || other) { fail = true; break; }
+                    }
+                }
+                if (fail) {
+                    if (lane == 0) {
+                        __hip_atomic_store(g_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_abort = 1;
+                    }
+                }
+                T acc = (T)0;
+#pragma unroll
+                for (int m = 0; m < Cfg::PM; ++m) acc += pv[m];
+                tot = wave_sum(acc);
+                if (lane < S) gh[0][lane] = want_l ? hv : (T)0;
+                if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = want_r ? hv : (T)0;
+            }
+            if (lane == 0) bc[epoch & 1] = tot;
+        }
+        __syncthreads();                                                       // B2
+        total = bc[epoch & 1];
+        aborted = s_abort != 0;
+    };
+
+    // ---- r~ = Pinv r ; p = r~ ; eta = r . r~   (gato_pcg.cuh:316-335) ------------------------
+    rt = row_times_window<T, S, SP>(pm, &xs[1][j * SP]);
+    allreduce_and_halo(rt, r * rt, eta);
+    if (!aborted) {
+        p = rt;
+        if (active) xs[0][(j + 1) * SP + r_] = p;
+        if (W > 1) {
+            if (tid < S) xs[0][tid] = gh[0][tid];
+            else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = gh[1][tid - S];
+        }
+        __syncthreads();
+
+        for (int it = 0; it < a.max_iters; ++it) {                              // gato_pcg.cuh:348
+            // upsilon = S p ; v = p . upsilon                                     (:349-357)
+            ups = row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
+            T v;
+            allreduce_and_halo(ups, p * ups, v);
+            if (aborted) break;
+            const T alpha = eta / v;                                            // :364
+            lam += alpha * p;                                                   // :373-377
+            r -= alpha * ups;
+            if (active) xs[1][(j + 1) * SP + r_] = r;
+            if (W > 1) {   // ghost r advances with the neighbours' upsilon blocks
+                if (tid < S) xs[1][tid] -= alpha * gh[0][tid];
+                else if (tid < 2 * S) xs[1][(nk + 1) * SP + (tid - S)] -= alpha * gh[1][tid - S];
+            }
+            __syncthreads();                                                    // B3
+            // r~ = Pinv r ; eta' = r . r~                                        (:380-394)
+            rt = row_times_window<T, S, SP>(pm, &xs[1][j * SP]);
+            allreduce_and_halo(rt, r * rt, eta_new);
+            if (aborted) break;
+            if (fabs(eta_new) < tol) { iters = it; break; }                     // :404-411
+            const T beta = eta_new / eta;                                       // :415
+            p = rt + beta * p;                                                  // :416-419
+            if (active) xs[0][(j + 1) * SP + r_] = p;
+            if (W > 1) {
+                if (tid < S) xs[0][tid] = gh[0][tid] + beta * xs[0][tid];
+                else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = gh[1][tid - S] + beta * xs[0][(nk + 1) * SP + (tid - S)];
+            }
+            eta = eta_new;                                                      // :420
+            __syncthreads();                                                    // B6
+        }
+    }
+    if (active) dL[(size_t)k * S + r_] = lam;                                   // :433-435
+    if (wg == 0 && tid == 0) {
+        *a.iters = iters;
+        if (a.final_eta) *a.final_eta = (double)eta_new;
+    }
+}
+
+template <typename T, int S> struct MaxThreads;
+// VGPR budget: 3S*2 matrix registers per lane (x2 for fp64).  launch bound -> registers per lane:
+// 1024 threads -> 128, 768 -> 168, 512 -> 256, 256 -> 512 (MI355X register file: 512 per lane per SIMD).
+// Chosen so that the matrix rows plus the 3S-wide operand window stay in registers without spilling.
+template <> struct MaxThreads<float, 2> { static constexpr int v = 1024; };
+template <> struct MaxThreads<double, 2> { static constexpr int v = 1024; };
+template <> struct MaxThreads<float, 14> { static constexpr int v = 768; };
+template <> struct MaxThreads<double, 14> { static constexpr int v = 512; };
+template <> struct MaxThreads<float, 32> { static constexpr int v = 512; };
+template <> struct MaxThreads<double, 32> { static constexpr int v = 256; };
+
+}  // namespace
+
+template <typename T, int S>
+int pcg_resident_plan(PcgPlan *plan)
+{
+    plan->max_threads = MaxThreads<T, S>::v;
+    plan->max_knots_per_wg = MaxThreads<T, S>::v / S;
+    return GATO_OK;
+}
+
+template <typename T, int S>
+int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
+{
+    constexpr int MAXT = MaxThreads<T, S>::v;
+    if (a.threads > MAXT || a.threads % 64 != 0 || a.threads < 2 * S || a.knots_per_wg * S > a.threads ||
+        a.groups < 1 || a.groups > 256 || (long long)a.groups * a.knots_per_wg < a.K ||
+        (long long)(a.groups - 1) * a.knots_per_wg >= a.K) {
+        set_error("pcg_resident: bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d max=%d)", a.K,
+                  a.groups, a.knots_per_wg, a.threads, MAXT);
+        return GATO_EINVAL;
+    }
+    const size_t slot_bytes = (size_t)2 * a.groups * pcg_slot_granules(S, (int)sizeof(T)) * 8;
+    if (a.groups > 1) GATO_HIP_CHECK(hipMemsetAsync(a.slots, 0, slot_bytes, st));
+    GATO_HIP_CHECK(hipMemsetAsync(a.status, 0, sizeof(int), st));
+    hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT>), dim3(a.groups), dim3(a.threads), 0, st, a);
+    GATO_HIP_CHECK(hipGetLastError());
+    return GATO_OK;
+}
+
+#define X(S_, C_)                                                      \
+    template int pcg_resident_plan<float, S_>(PcgPlan *);              \
+    template int pcg_resident_plan<double, S_>(PcgPlan *);             \
+    template int launch_pcg_resident<float, S_>(const PcgLaunch &, hipStream_t); \
+    template int launch_pcg_resident<double, S_>(const PcgLaunch &, hipStream_t);
+GATO_SHAPES(X)
+#undef X
+
+}  // namespace gato

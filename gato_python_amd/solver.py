@@ -1,0 +1,131 @@
+"""Device-resident solver object over the C ABI (include/gato_hip.h).
+
+Mirrors the reference's per-solve driver gato_linsys (gpu_library.cu:25-83) and the three
+launch wrappers it calls - form_schur (src/gato_schur.cuh:885-1009), solve_pcg
+(src/gato_pcg.cuh:476-567), compute_dz (src/gato_schur.cuh:1012-1022) - with the same stage
+names, on device buffers.  torch is used only to hold device memory and name the stream.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_TORCH_DT = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        assert t.is_cuda and t.is_contiguous()
+        return ct.c_void_p(t.data_ptr())
+    return ct.c_void_p(int(t))
+
+
+class Solver:
+    """Workspace + kernels for one (STATE_SIZE, CONTROL_SIZE, KNOT_POINTS, dtype) on one GPU."""
+
+    def __init__(self, S: int, C: int, K: int, dtype=np.float32, device: int = 0):
+        self.S, self.C, self.K = int(S), int(C), int(K)
+        self.np_dtype = np.dtype(dtype)
+        self.dtype = _TORCH_DT[self.np_dtype]
+        self.device = int(device)
+        self._h = ct.c_void_p()
+        code = _lib.GATO_F32 if self.np_dtype == np.float32 else _lib.GATO_F64
+        _lib.check(_lib.lib().gato_solver_create(self.S, self.C, self.K, code, self.device, ct.byref(self._h)))
+        self.n = self.S + self.C
+        self.N = self.n * self.K - self.C
+        self.sizes = dict(G_dense=(S * S + C * C) * K - C * C, C_dense=(S * S + S * C) * (K - 1),
+                          bd=3 * S * S * K, sk=S * K)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib().gato_solver_destroy(self._h)
+            self._h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- options -------------------------------------------------------------------------
+    def set_option(self, name: str, value: int):
+        _lib.check(_lib.lib().gato_solver_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = ct.c_int()
+        _lib.check(_lib.lib().gato_solver_get_option(self._h, name.encode(), ct.byref(v)))
+        return v.value
+
+    def _stream(self):
+        return ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def new(self, n, dtype=None):
+        return torch.empty(int(n), dtype=dtype or self.dtype, device=f"cuda:{self.device}")
+
+    def to_device(self, a, dtype=None):
+        a = np.ascontiguousarray(a, dtype or self.np_dtype)
+        return torch.from_numpy(a).to(f"cuda:{self.device}")
+
+    # ---- stages (device tensors in, device tensors out) -------------------------------------
+    def convert(self, G_row, G_col, G_val, C_row, C_col, C_val, rho):
+        Gd, Cd = self.new(self.sizes["G_dense"]), self.new(max(self.sizes["C_dense"], 1))
+        _lib.check(_lib.lib().gato_convert(self._h, _ptr(G_row), _ptr(G_col), _ptr(G_val), _ptr(C_row),
+                                           _ptr(C_col), _ptr(C_val), float(rho), _ptr(Gd), _ptr(Cd),
+                                           self._stream()))
+        return Gd, Cd[: self.sizes["C_dense"]]
+
+    def form_schur(self, Gd, Cd, g, c):
+        Sb, Pb = self.new(self.sizes["bd"]), self.new(self.sizes["bd"])
+        gam, Gi = self.new(self.sizes["sk"]), self.new(self.sizes["G_dense"])
+        _lib.check(_lib.lib().gato_form_schur(self._h, _ptr(Gd), _ptr(Cd), _ptr(g), _ptr(c), _ptr(Sb),
+                                              _ptr(Pb), _ptr(gam), _ptr(Gi), self._stream()))
+        return Sb, Pb, gam, Gi
+
+    def form_ss(self, Sb, Pb):
+        _lib.check(_lib.lib().gato_form_ss(self._h, _ptr(Sb), _ptr(Pb), self._stream()))
+        return Pb
+
+    def pcg(self, Sb, Pb, gamma, exit_tol, max_iters, lam=None, iters=None, check=True):
+        lam = self.new(self.sizes["sk"]) if lam is None else lam
+        iters = self.new(1, torch.int32) if iters is None else iters
+        _lib.check(_lib.lib().gato_pcg(self._h, _ptr(Sb), _ptr(Pb), _ptr(gamma), _ptr(lam), float(exit_tol),
+                                       int(max_iters), _ptr(iters), self._stream()))
+        if check:
+            torch.cuda.current_stream(self.device).synchronize()
+            _lib.check(_lib.lib().gato_pcg_status(self._h, None))
+        return lam, iters
+
+    def compute_dz(self, Gi, Cd, g, lam):
+        dz = self.new(self.N)
+        _lib.check(_lib.lib().gato_compute_dz(self._h, _ptr(Gi), _ptr(Cd), _ptr(g), _ptr(lam), _ptr(dz),
+                                              self._stream()))
+        return dz
+
+    # ---- whole solve on device-resident CSR (gato_linsys, gpu_library.cu:25-83) ----------------
+    def linsys(self, G_row, G_col, G_val, C_row, C_col, C_val, g, c, exit_tol, max_iters, rho,
+               lam=None, dz=None):
+        _lib.check(_lib.lib().gato_linsys_device(self._h, _ptr(G_row), _ptr(G_col), _ptr(G_val), _ptr(C_row),
+                                                 _ptr(C_col), _ptr(C_val), _ptr(g), _ptr(c), float(exit_tol),
+                                                 int(max_iters), float(rho), _ptr(lam), _ptr(dz),
+                                                 self._stream()))
+
+    def buffer_ptr(self, which: int) -> int:
+        return int(_lib.lib().gato_solver_buffer(self._h, which))
+
+    def check_status(self):
+        _lib.check(_lib.lib().gato_pcg_status(self._h, None))
+
+    def upload_system(self, sysm):
+        """KKTSystem (host CSR) -> tuple of device tensors in linsys() argument order."""
+        i32 = torch.int32
+        dev = f"cuda:{self.device}"
+        t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+        return (t(sysm.G_row, np.int32), t(sysm.G_col, np.int32), t(sysm.G_val, self.np_dtype),
+                t(sysm.C_row, np.int32), t(sysm.C_col, np.int32), t(sysm.C_val, self.np_dtype),
+                t(sysm.g, self.np_dtype), t(sysm.c, self.np_dtype))

@@ -1,0 +1,125 @@
+/* gato_hip.h - C ABI of the MI355X-native gato PCG / Schur hot path (libgato_hip.so).
+ *
+ * Drop-in boundary: these entry points are what the reference's binding layer would call
+ * instead of its CUDA driver.  Every function cites the reference interface it replaces
+ * (file:line relative to the reference checkout).  Plain pointers and sizes only; no torch
+ * or pybind11 types.  All functions return 0 on success or a negative GATO_E* code, and
+ * gato_last_error() gives the message (the reference prints "GPUassert" and exit()s,
+ * include/gato_defines.h:42-51).
+ *
+ * Conventions:  S = STATE_SIZE, C = CONTROL_SIZE, K = KNOT_POINTS (runtime here; compile-time
+ * macros in the reference, CMakeLists.txt:18), n = S+C, N = n*K - C.
+ * dtype: GATO_F32 (the reference's only arithmetic type) or GATO_F64.  `void*` data pointers
+ * are float* or double* according to the solver's dtype.  Device layouts are the reference's:
+ *   G_dense : per knot [Q_k S*S | R_k C*C] col-major, last knot Q only  ((S*S+C*C)*K - C*C elems, gato_defines.h:36)
+ *   C_dense : per knot k<K-1 [A_k S*S | B_k S*C] col-major              ((S*S+S*C)*(K-1) elems, gato_defines.h:37)
+ *   S, Pinv : per block-row [left|main|right], each S*S col-major       (3*S*S*K elems, gato_utils.cuh:44-73)
+ *   gamma, lambda : S*K ; g, dz : N ; c : S*K
+ * `stream` is a hipStream_t passed as void* (NULL = default stream, as the reference uses,
+ * gato_defines.h:22).
+ */
+#ifndef GATO_HIP_H
+#define GATO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GATO_F32 0
+#define GATO_F64 1
+
+#define GATO_OK 0
+#define GATO_EINVAL (-1)   /* bad argument / shape mismatch */
+#define GATO_ESHAPE (-2)   /* (S,C) has no compiled instantiation */
+#define GATO_EHIP (-3)     /* HIP runtime error */
+#define GATO_ENODEV (-4)   /* no usable GPU */
+#define GATO_ETIMEOUT (-5) /* in-kernel hand-off timed out (persistent PCG) */
+
+/* PCG kernel selection (gato_pcg.cuh:505-553 picks K4 vs K5 by co-residency, check_sms) */
+#define GATO_PCG_AUTO 0
+#define GATO_PCG_RESIDENT 1  /* A5: matrices register-resident for the whole solve, one persistent launch */
+#define GATO_PCG_STREAMING 2 /* A6: matrices re-read from HBM every iteration, two launches per iteration */
+
+typedef struct gato_solver gato_solver;
+
+/* ---- library / device ------------------------------------------------------------------- */
+const char *gato_last_error(void);
+int gato_version(void);
+/* Number of (S,C) instantiations compiled in, and the i-th one. */
+int gato_num_shapes(void);
+int gato_shape(int i, int *S, int *C);
+/* Replaces check_sms (gato_utils.cuh:829-854): device properties needed to size the grids. */
+int gato_device_info(int device, int *num_cus, int *lds_bytes, char *name, int name_len);
+
+/* Infers (S,C,K) from the lengths of the linsys_solve arguments (the reference gets them from
+ * -DSTATE_SIZE/-DCONTROL_SIZE/-DKNOT_POINTS, install.bash:6-16): S*K = len_c, N = len_g, and
+ * S = number of leading single-entry identity rows of C (row-block 0 of C, gato_schur.cuh:725). */
+int gato_infer_shape(const int *C_row, int len_C_row, int len_g, int len_c, int *S, int *C, int *K);
+
+/* ---- solver object: owns the device workspace the reference allocates per call
+ * (gpu_library.cu:36-45, gato_pcg.cuh:486-492) -------------------------------------------- */
+int gato_solver_create(int S, int C, int K, int dtype, int device, gato_solver **out);
+int gato_solver_destroy(gato_solver *s);
+/* Workspace device pointers (valid for the solver's lifetime), for stage-level tests:
+ * which: 0 G_dense, 1 C_dense, 2 Ginv_dense, 3 S, 4 Pinv, 5 gamma, 6 lambda, 7 dz, 8 iters(int) */
+void *gato_solver_buffer(gato_solver *s, int which);
+/* Options: pcg_mode (GATO_PCG_*), pcg_threads (0 = auto; threads per workgroup of the resident
+ * kernel), pcg_groups (0 = auto; workgroups of the resident kernel). */
+int gato_solver_set_option(gato_solver *s, const char *name, int value);
+int gato_solver_get_option(gato_solver *s, const char *name, int *value);
+
+/* ---- stage-level entry points on DEVICE pointers (one per reference launch wrapper) ------ */
+/* A1  form_schur's first launch, gato_convert_kkt_format (gato_schur.cuh:745-756, :902).
+ * Zeroes G_dense/C_dense itself (the reference relies on cuda_calloc, gpu_library.cu:36-37). */
+int gato_convert(gato_solver *s, const int *d_G_row, const int *d_G_col, const void *d_G_val,
+                 const int *d_C_row, const int *d_C_col, const void *d_C_val, double rho,
+                 void *d_G_dense, void *d_C_dense, void *stream);
+/* A2  gato_form_schur_jacobi (gato_schur.cuh:462-494, :942).  Writes S (left, main, right),
+ * Pinv.main, gamma and the inverses Q^-1,R^-1 into d_Ginv_dense (separate buffer; the
+ * reference overwrites d_G_dense in place, :238-259, racing with its neighbours - D3). */
+int gato_form_schur(gato_solver *s, const void *d_G_dense, const void *d_C_dense, const void *d_g,
+                    const void *d_c, void *d_S, void *d_Pinv, void *d_gamma, void *d_Ginv_dense,
+                    void *stream);
+/* A3  gato_form_ss (gato_schur.cuh:652-670, :967): Pinv.left / Pinv.right. */
+int gato_form_ss(gato_solver *s, const void *d_S, void *d_Pinv, void *stream);
+/* A4-A8  solve_pcg<T> (gato_pcg.cuh:476-567).  lambda is reset to 0 (D5: warm_start is a no-op in
+ * the reference, gato_pcg.cuh:303).  d_iters receives the reference's iteration count (index of
+ * the iteration that met |eta| < exit_tol, else max_iters; gato_pcg.cuh:311-313,:406-408).
+ * Asynchronous on `stream`; gato_pcg_status() after synchronising reports hand-off timeouts. */
+int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma,
+             void *d_lambda, double exit_tol, int max_iters, int *d_iters, void *stream);
+int gato_pcg_status(gato_solver *s, int *status);
+/* A9  compute_dz (gato_schur.cuh:1012-1022) with d_Ginv_dense = inverses from gato_form_schur. */
+int gato_compute_dz(gato_solver *s, const void *d_Ginv_dense, const void *d_C_dense, const void *d_g,
+                    const void *d_lambda, void *d_dz, void *stream);
+
+/* ---- A13  gato_linsys (gpu_library.cu:25-83) on DEVICE CSR inputs: convert, Schur, stair,
+ * PCG, dz, all on `stream`, into the solver's workspace; d_lambda/d_dz may be NULL (results stay
+ * in the workspace, gato_solver_buffer 6/7).  Asynchronous. */
+int gato_linsys_device(gato_solver *s, const int *d_G_row, const int *d_G_col, const void *d_G_val,
+                       const int *d_C_row, const int *d_C_col, const void *d_C_val,
+                       const void *d_g, const void *d_c, double exit_tol, int max_iters, double rho,
+                       void *d_lambda, void *d_dz, void *stream);
+
+/* ---- L4  main_call (gpu_library.cu:85-234) on HOST pointers: H2D of the CSR, `testiters`
+ * timed repeats of the whole solve, D2H of lambda and dz.  ms_out[testiters] (may be NULL)
+ * receives the per-repeat time the reference prints (gpu_library.cu:186-198).
+ * lambda_in is read only when warm_start != 0 and then ignored by the PCG exactly as the
+ * reference does (D5). */
+int gato_linsys_solve_f32(const int *G_row, int len_G_row, const int *G_col, const float *G_val, int nnz_G,
+                          const int *C_row, int len_C_row, const int *C_col, const float *C_val, int nnz_C,
+                          const float *g, int len_g, const float *c, int len_c, const float *lambda_in,
+                          int S, int C, int K, int testiters, float exit_tol, int max_iters,
+                          int warm_start, float rho, float *lambda_out, float *dz_out,
+                          int *iters_out, float *ms_out);
+int gato_linsys_solve_f64(const int *G_row, int len_G_row, const int *G_col, const double *G_val, int nnz_G,
+                          const int *C_row, int len_C_row, const int *C_col, const double *C_val, int nnz_C,
+                          const double *g, int len_g, const double *c, int len_c, const double *lambda_in,
+                          int S, int C, int K, int testiters, double exit_tol, int max_iters,
+                          int warm_start, double rho, double *lambda_out, double *dz_out,
+                          int *iters_out, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GATO_HIP_H */

@@ -1,0 +1,92 @@
+"""CPU suite: the C-ABI library loads, exports every symbol include/gato_hip.h declares, and the
+host logic (shape inference, argument validation) behaves - no compute calls without a GPU."""
+import ctypes as ct
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gato_python_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "gato_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gato_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/gato_hip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_compiled_shapes():
+    assert (2, 1) in _lib.shapes() and (14, 7) in _lib.shapes() and (32, 16) in _lib.shapes()
+
+
+@pytest.mark.parametrize("S,C,K", [(2, 1, 5), (14, 7, 50), (32, 16, 7), (14, 7, 2)])
+def test_infer_shape(S, C, K):
+    s = synth.make_system(S, C, K, seed=0)
+    a, b, c = ct.c_int(), ct.c_int(), ct.c_int()
+    rc = _lib.lib().gato_infer_shape(s.C_row.ctypes.data_as(ct.c_void_p), len(s.C_row), len(s.g), len(s.c),
+                                     ct.byref(a), ct.byref(b), ct.byref(c))
+    assert rc == 0 and (a.value, b.value, c.value) == (S, C, K)
+
+
+def test_infer_shape_pendulum_literals():
+    p = synth.pendulum_system()
+    a, b, c = ct.c_int(), ct.c_int(), ct.c_int()
+    rc = _lib.lib().gato_infer_shape(p.C_row.ctypes.data_as(ct.c_void_p), len(p.C_row), len(p.g), len(p.c),
+                                     ct.byref(a), ct.byref(b), ct.byref(c))
+    assert rc == 0 and (a.value, b.value, c.value) == (2, 1, 5)
+
+
+def test_infer_shape_rejects_inconsistent_lengths():
+    p = synth.pendulum_system()
+    a, b, c = ct.c_int(), ct.c_int(), ct.c_int()
+    rc = _lib.lib().gato_infer_shape(p.C_row.ctypes.data_as(ct.c_void_p), len(p.C_row) - 1, len(p.g), len(p.c),
+                                     ct.byref(a), ct.byref(b), ct.byref(c))
+    assert rc == -1 and b"len(C_row)" in _lib.lib().gato_last_error()
+
+
+def test_unknown_shape_is_an_error_not_a_fallback():
+    import gpu_library
+    with pytest.raises(ValueError, match="not a compiled shape"):
+        gpu_library.linsys_solve([0, 1], [0], [1.], [0, 1], [0], [1.], [1.], [0.], [0.], 1, 1e-6, 10, False, 1e-3)
+
+
+def test_short_input_lambda_rejected():
+    import gpu_library
+    P = synth.PENDULUM
+    with pytest.raises(ValueError, match="input_lambda"):
+        gpu_library.linsys_solve(P["G_row"], P["G_col"], P["G_val"], P["C_row"], P["C_col"], P["C_val"],
+                                 P["g_val"], P["c_val"], [0.] * 3, 1, 1e-6, 10, False, 1e-3)
+
+
+def test_no_gpu_fails_loudly():
+    """Without a GPU the product path must raise, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import gpu_library
+    P = synth.PENDULUM
+    with pytest.raises(_lib.GatoError, match="ENODEV|EHIP"):
+        gpu_library.linsys_solve(P["G_row"], P["G_col"], P["G_val"], P["C_row"], P["C_col"], P["C_val"],
+                                 P["g_val"], P["c_val"], P["input_lambda"], 1, 1e-6, 10, False, 1e-3)
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gato_python_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "libgato_oracle" not in txt, f
+    assert "oracle" not in open(os.path.join(ROOT, "gpu_library.py")).read().replace("KKT oracle", "")

@@ -1,0 +1,262 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the oracle on the same seeded
+inputs, against the committed golden fixtures, and - at BASELINE's full sizes - through
+size-independent properties (KKT residuals, determinism, resident == streaming).
+
+Tolerances: CSR scatter is bit-exact.  fp64 stages: 1e-11 relative (same formulas, different
+summation order only in the wave-parallel dots).  fp32 stages: 2e-4 relative on assembled blocks
+(Gauss-Jordan without pivoting amplifies rounding by cond(theta)), PCG compared at a fixed
+iteration count.  BASELINE's bar, ||dz - dz_ref||inf < 1e-6 and lambda within 1e-6 relative, is
+asserted in fp64 against the dense KKT solve.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from gato_python_amd import _lib, synth          # noqa: E402
+from oracle import c_oracle as co                # noqa: E402
+from oracle import gato_oracle as o              # noqa: E402
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU suite needs a GPU"
+    _lib.lib()                                    # the HIP library must be the thing that runs
+
+
+def make_solver(S, C, K, dt):
+    from gato_python_amd.solver import Solver
+    return Solver(S, C, K, dt)
+
+
+def system(S, C, K, seed=0, dq=False):
+    if (S, C, K) == (2, 1, 5) and seed == -1:
+        return synth.pendulum_system()
+    return synth.make_system(S, C, K, seed=seed, dense_q=dq)
+
+
+CASES = [(2, 1, 5, -1, False), (2, 1, 2, 0, False), (2, 1, 1, 0, False), (14, 7, 50, 0, False), (14, 7, 7, 1, True),
+         (32, 16, 12, 5, True), (2, 1, 700, 2, True)]
+
+
+@pytest.mark.parametrize("S,C,K,seed,dq", CASES)
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_every_stage_against_oracle(S, C, K, seed, dq, dt):
+    s = system(S, C, K, seed, dq) if K > 1 else synth.blocks_to_csr(*synth.make_blocks(S, C, 1, seed, dq))
+    sol = make_solver(S, C, K, dt)
+    dev = sol.upload_system(s)
+    f64 = dt == np.float64
+    tol_blk = 1e-11 if f64 else 3e-4
+    # A1 convert: bit-exact
+    Gd, Cd = sol.convert(*dev[:6], s.rho)
+    Gd_o, Cd_o = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
+    assert np.array_equal(host(Gd), Gd_o) and np.array_equal(host(Cd), Cd_o)
+    # A2 Schur / block-Jacobi / gamma / inverses
+    Sb, Pb, gam, Gi = sol.form_schur(Gd, Cd, dev[6], dev[7])
+    Sb_o, Pb_o, gam_o, Gi_o = co.form_schur(Gd_o, Cd_o, s.g, s.c, S, C, K)
+    assert rel(host(Gi), Gi_o) < tol_blk and rel(host(Sb), Sb_o) < tol_blk
+    assert rel(host(Pb), Pb_o) < tol_blk and rel(host(gam), gam_o) < tol_blk
+    # A3 stair off-diagonals (fed with the oracle's inputs so the stage is isolated)
+    Pb2 = sol.form_ss(sol.to_device(Sb_o), sol.to_device(Pb_o))
+    Pb2_o = co.form_ss(Sb_o, Pb_o, S, K)
+    assert rel(host(Pb2), Pb2_o) < (1e-12 if f64 else 2e-5)
+    # A5 PCG on the oracle's S, Pinv, gamma: fixed iteration count
+    n_it = 8
+    lam, it = sol.pcg(sol.to_device(Sb_o), sol.to_device(Pb2_o), sol.to_device(gam_o), 0.0, n_it)
+    lam_o, it_o = co.pcg(Sb_o, Pb2_o, gam_o, S, K, 0.0, n_it)
+    assert int(host(it)[0]) == it_o == n_it
+    if np.all(np.isfinite(lam_o)):
+        assert rel(host(lam), lam_o) < (1e-10 if f64 else 2e-3)
+    # A9 dz on the oracle's lambda
+    lam_c, _ = co.pcg(Sb_o, Pb2_o, gam_o, S, K, 1e-8, 200)
+    dz = sol.compute_dz(sol.to_device(Gi_o), sol.to_device(Cd_o) if K > 1 else sol.new(1), dev[6], sol.to_device(lam_c))
+    dz_o = co.compute_dz(Gi_o, Cd_o, s.g, lam_c, S, C, K)
+    assert rel(host(dz), dz_o) < (1e-12 if f64 else 2e-5)
+    sol.close()
+
+
+def test_pendulum_golden_through_the_dropin(golden_dir):
+    """The reference's own test (test_pendulum_5.py) run against this build, with its assertion."""
+    import gpu_library
+    gold = json.load(open(os.path.join(golden_dir, "pendulum.json")))
+    i, e = gold["inputs"], gold["expected"]
+    gpu_library.clear_problem_size()
+    args = (i["G_row"], i["G_col"], i["G_val"], i["C_row"], i["C_col"], i["C_val"], i["g_val"], i["c_val"],
+            i["input_lambda"], i["testiters"], i["exit_tol"], i["max_iters"], i["warm_start"], i["rho"])
+    l, dz = gpu_library.linsys_solve(*args)
+    assert isinstance(l, list) and isinstance(dz, list) and len(l) == 10 and len(dz) == 14
+    st = gpu_library.last_stats()
+    assert st["iters"] == e["iters_f32"] and (st["S"], st["C"], st["K"]) == (2, 1, 5) and len(st["ms"]) == 10
+    x = np.concatenate([e["dense_kkt_norho_dz"], e["dense_kkt_norho_lam"]])
+    assert np.allclose(np.concatenate([dz, l]), x, rtol=1, atol=0.01)          # test_pendulum_5.py:37
+    assert rel(l, e["lam"]) < 5e-5 and np.abs(np.asarray(dz) - e["dz"]).max() < 5e-3
+    gpu_library.set_precision("f64")
+    try:
+        l, dz = gpu_library.linsys_solve(*args)
+        assert gpu_library.last_stats()["iters"] == e["iters_f64"]
+        assert rel(l, e["lam"]) < 1e-11 and np.abs(np.asarray(dz) - e["dz"]).max() < 1e-9
+        assert rel(l, e["dense_kkt_lam"]) < 1e-9
+    finally:
+        gpu_library.set_precision("f32")
+
+
+@pytest.mark.parametrize("name,S,C,K,seed,dq,tol,mi", [("iiwa_14_7_50_seed0.npz", 14, 7, 50, 0, False, 1e-6, 100),
+                                                       ("s32_c16_k12_seed5_denseq.npz", 32, 16, 12, 5, True, 1e-12, 500)])
+def test_golden_fp64_whole_solve(golden_dir, name, S, C, K, seed, dq, tol, mi):
+    gold = np.load(os.path.join(golden_dir, name))
+    s = synth.make_system(S, C, K, seed=seed, dense_q=dq)
+    sol = make_solver(S, C, K, np.float64)
+    dev = sol.upload_system(s)
+    lam, dz = sol.new(S * K), sol.new(sol.N)
+    sol.linsys(*dev, tol, mi, s.rho, lam, dz)
+    torch.cuda.synchronize()
+    sol.check_status()
+    assert rel(host(lam), gold["lam"]) < 1e-9 and rel(host(dz), gold["dz"]) < 1e-9
+    if "lam_tight" in gold:                     # BASELINE bar against the dense KKT solve
+        sol.linsys(*dev, 1e-15, 1000, s.rho, lam, dz)
+        torch.cuda.synchronize()
+        assert rel(host(lam), gold["dense_lam"]) < 1e-6
+        assert np.abs(host(dz) - gold["dense_dz"]).max() < 1e-6
+    sol.close()
+
+
+@pytest.mark.parametrize("S,C,K,dt,opts", [
+    (14, 7, 50, np.float32, {}),                                  # one workgroup
+    (14, 7, 50, np.float64, {}),                                  # two workgroups (register budget)
+    (14, 7, 50, np.float32, dict(pcg_groups=7)),                  # forced ragged split
+    (14, 7, 50, np.float64, dict(pcg_threads=64)),                # 4 knots per workgroup, 13 groups
+    (14, 7, 512, np.float32, {}),
+    (14, 7, 512, np.float64, {}),
+    (14, 7, 4096, np.float32, {}),
+    (14, 7, 4096, np.float64, {}),
+    (32, 16, 1024, np.float32, {}),
+    (32, 16, 256, np.float64, {}),
+    (2, 1, 3000, np.float32, dict(pcg_threads=128)),
+    (14, 7, 512, np.float32, dict(pcg_mode=_lib.PCG_STREAMING)),
+    (14, 7, 777, np.float64, dict(pcg_mode=_lib.PCG_STREAMING)),
+    (32, 16, 100, np.float32, dict(pcg_mode=_lib.PCG_STREAMING)),
+    (2, 1, 5000, np.float64, dict(pcg_mode=_lib.PCG_STREAMING)),
+])
+def test_pcg_variants_against_oracle(S, C, K, dt, opts):
+    """Resident (1..W workgroups, in-launch hand-offs) and streaming PCG vs the C oracle on the same
+    S, Pinv, gamma: same iteration count at exit_tol, lambda equal to rounding."""
+    s = synth.make_system(S, C, K, seed=11)
+    Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
+    Sb, Pb, gam, Gi = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+    Pb = co.form_ss(Sb, Pb, S, K)
+    sol = make_solver(S, C, K, dt)
+    for k, v in opts.items():
+        sol.set_option(k, v)
+    f64 = dt == np.float64
+    dS, dP, dg = sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam)
+    # fixed number of iterations
+    lam, it = sol.pcg(dS, dP, dg, 0.0, 12)
+    lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, 0.0, 12)
+    assert int(host(it)[0]) == 12
+    assert rel(host(lam), lam_o) < (1e-10 if f64 else 5e-3)
+    # run to tolerance: iteration count of the reference's exit test
+    tol = 1e-8 if f64 else 1e-4
+    lam, it = sol.pcg(dS, dP, dg, tol, 300)
+    lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, tol, 300)
+    assert abs(int(host(it)[0]) - it_o) <= (0 if f64 else 2), (int(host(it)[0]), it_o)
+    assert rel(host(lam), lam_o) < (1e-9 if f64 else 5e-3)
+    # deterministic: bitwise identical on a second run
+    lam2, it2 = sol.pcg(dS, dP, dg, tol, 300)
+    assert torch.equal(lam, lam2) and torch.equal(it, it2)
+    mode = sol.get_option("last_mode")
+    assert mode == opts.get("pcg_mode", _lib.PCG_RESIDENT)
+    if "pcg_groups" in opts:
+        assert sol.get_option("last_groups") >= opts["pcg_groups"]
+    sol.close()
+
+
+def test_unused_boundary_blocks_are_never_read():
+    """S[0].left and S[K-1].right are unwritten garbage in the reference (gpu_library.cu:40-41): the PCG
+    must not touch them (gato_utils.cuh:157-174)."""
+    S, C, K = 14, 7, 40
+    s = synth.make_system(S, C, K, seed=4)
+    Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, np.float64)
+    Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+    Pb = co.form_ss(Sb, Pb, S, K)
+    lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, 1e-10, 200)
+    Sb[:S * S] = np.nan
+    Pb[:S * S] = np.nan
+    Sb[-S * S:] = np.nan
+    Pb[-S * S:] = np.nan
+    for mode in (_lib.PCG_RESIDENT, _lib.PCG_STREAMING):
+        sol = make_solver(S, C, K, np.float64)
+        sol.set_option("pcg_mode", mode)
+        lam, it = sol.pcg(sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam), 1e-10, 200)
+        assert int(host(it)[0]) == it_o and rel(host(lam), lam_o) < 1e-9
+        sol.close()
+
+
+@pytest.mark.parametrize("S,C,K,dt", [(14, 7, 4096, np.float64), (14, 7, 4096, np.float32), (32, 16, 1024, np.float64)])
+def test_full_size_properties(S, C, K, dt):
+    """BASELINE sizes: the returned (lambda, dz) satisfy the KKT equations
+         (G + rho I) dz + C^T lambda = g,   C dz = c
+    to solver tolerance (sparse fp64 residuals on the host), resident == streaming, and the iteration
+    count equals the oracle's."""
+    from scipy import sparse
+    s = synth.make_system(S, C, K, seed=21)
+    sol = make_solver(S, C, K, dt)
+    dev = sol.upload_system(s)
+    f64 = dt == np.float64
+    tol, mi = (1e-12, 400) if f64 else (1e-5, 200)
+    lam, dz = sol.new(S * K), sol.new(sol.N)
+    sol.linsys(*dev, tol, mi, s.rho, lam, dz)
+    torch.cuda.synchronize()
+    sol.check_status()
+    G = sparse.csr_matrix((s.G_val, s.G_col, s.G_row), shape=(s.N, s.N)) + s.rho * sparse.identity(s.N)
+    Cm = sparse.csr_matrix((s.C_val, s.C_col, s.C_row), shape=(S * K, s.N))
+    l, d = host(lam).astype(np.float64), host(dz).astype(np.float64)
+    r1 = G @ d + Cm.T @ l - s.g
+    r2 = Cm @ d - s.c
+    scale = max(np.abs(s.g).max(), np.abs(l).max())
+    assert np.abs(r1).max() / scale < (1e-10 if f64 else 1e-4)
+    assert np.abs(r2).max() < (1e-6 if f64 else 5e-2)
+    lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
+    assert rel(l, lam_o) < (1e-8 if f64 else 2e-2)
+    # streaming variant gives the same answer
+    sol2 = make_solver(S, C, K, dt)
+    sol2.set_option("pcg_mode", _lib.PCG_STREAMING)
+    lam2, dz2 = sol2.new(S * K), sol2.new(sol2.N)
+    sol2.linsys(*dev, tol, mi, s.rho, lam2, dz2)
+    torch.cuda.synchronize()
+    assert rel(host(lam2), l) < (1e-8 if f64 else 2e-2)
+    sol.close()
+    sol2.close()
+
+
+def test_dropin_accepts_numpy_and_env_shape(monkeypatch):
+    import gpu_library
+    s = synth.make_system(14, 7, 50, seed=0)
+    gpu_library.set_problem_size(14, 7, 50)
+    try:
+        l, dz = gpu_library.linsys_solve(s.G_row, s.G_col, s.G_val, s.C_row, s.C_col, s.C_val, s.g, s.c,
+                                         np.zeros(700), 2, 1e-6, 100, False, s.rho)
+    finally:
+        gpu_library.clear_problem_size()
+    lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), 14, 7, 50, 1e-6, 100, s.rho, dtype=np.float32)
+    assert abs(gpu_library.last_stats()["iters"] - it_o) <= 2
+    assert rel(l, lam_o) < 5e-3 and rel(dz, dz_o) < 5e-3
+    with pytest.raises(ValueError):
+        gpu_library.set_problem_size(14, 7, 49)
+        try:
+            gpu_library.linsys_solve(s.G_row, s.G_col, s.G_val, s.C_row, s.C_col, s.C_val, s.g, s.c,
+                                     np.zeros(700), 1, 1e-6, 100, False, s.rho)
+        finally:
+            gpu_library.clear_problem_size()
