@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py - PCG iterations/s of the gato hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-sweep] [--no-cpu]
+
+A step = one pass of the hot path over one synthetic KKT system already resident in HBM:
+CSR->dense scatter, Schur/preconditioner assembly, PCG with exit_tol = 0 (exactly max_iters = 100
+iterations, BASELINE.json configs[1]) and the dz back-substitution - gato_linsys of the reference
+(gpu_library.cu:25-83) through the C ABI (gato_linsys_device).  value = PCG iterations / second
+over the whole step.  `roofline` is for the dominant kernel (the PCG launch), timed with HIP events
+recorded on the launch stream right around it: ALGORITHMIC bytes per iteration
+B_iter = [(6K-4) S^2 + 13 S K] w x iterations / launch time, against 8 TB/s.
+`cpu_baseline` = the C restatement of the same step (oracle/, "port") on the host cores.
+
+N = 1 runs BASELINE.json configs[1] (IIWA 14/7, K = 50, fp64).  N > 1 runs configs[3]: one K = 4096
+system with its knots sharded over the N ranks (RCCL all-gathers of [partial dot | boundary blocks],
+gato_python_amd/dist.py), strong scaling.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 measured copy)
+
+WORKLOADS = {
+    # name: (S, C, K, dtype, BASELINE.json config)
+    "iiwa_14_7_k50_f64": (14, 7, 50, np.float64, "configs[1]"),
+    "iiwa_14_7_k50_f32": (14, 7, 50, np.float32, "configs[1] in the reference's fp32"),
+    "iiwa_14_7_k512_f32": (14, 7, 512, np.float32, "configs[2]"),
+    "iiwa_14_7_k4096_f32": (14, 7, 4096, np.float32, "configs[3] on one GPU"),
+    "iiwa_14_7_k4096_f64": (14, 7, 4096, np.float64, "configs[3] on one GPU, fp64"),
+    "s32_c16_k1024_f32": (32, 16, 1024, np.float32, "configs[4]"),
+}
+MAX_ITERS = 100
+
+
+def b_iter(S, K, w):
+    return ((6 * K - 4) * S * S + 13 * S * K) * w
+
+
+def dtype_name(dt):
+    return "f64" if np.dtype(dt) == np.float64 else "f32"
+
+
+def run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20):
+    from gato_python_amd import synth
+    from gato_python_amd.solver import Solver
+    S, C, K, dt, _ = WORKLOADS[name]
+    sysm = synth.make_system(S, C, K, seed=0)
+    sol = Solver(S, C, K, dt)
+    if pcg_mode is not None:
+        sol.set_option("pcg_mode", pcg_mode)
+    dev = sol.upload_system(sysm)
+    lam, dz = sol.new(S * K), sol.new(sol.N)
+
+    def step():
+        sol.linsys(*dev, 0.0, MAX_ITERS, sysm.rho, lam, dz)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    sol.check_status()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt_s = time.perf_counter() - t0
+    sol.check_status()
+
+    # dominant kernel: the PCG launch, HIP events on its stream right around the launch
+    sol.set_option("time_pcg", 1)
+    Sb = torch.empty(0)
+    import ctypes as ct
+    bufs = [sol.buffer_ptr(i) for i in (3, 4, 5)]
+    ms = []
+    for i in range(pcg_reps + 3):
+        sol.pcg(bufs[0], bufs[1], bufs[2], 0.0, MAX_ITERS, lam=lam, check=False)
+        v = sol.pcg_last_ms()
+        if i >= 3:
+            ms.append(v)
+    sol.set_option("time_pcg", 0)
+    pcg_ms = float(np.mean(ms))
+    bytes_launch = b_iter(S, K, np.dtype(dt).itemsize) * MAX_ITERS
+    res = dict(
+        workload=name, S=S, C=C, K=K, dtype=dtype_name(dt),
+        iters_per_s=MAX_ITERS * steps / dt_s, ms_per_step=1e3 * dt_s / steps,
+        pcg_launch_ms=pcg_ms, pcg_launch_ms_min=float(np.min(ms)),
+        pcg_iters_per_s=MAX_ITERS / (pcg_ms * 1e-3),
+        pcg_mode={1: "resident", 2: "streaming"}.get(sol.get_option("last_mode")),
+        pcg_groups=sol.get_option("last_groups"), pcg_threads=sol.get_option("last_threads"),
+        algorithmic_bytes_per_launch=bytes_launch,
+        achieved_gbs=bytes_launch / (pcg_ms * 1e-3) / 1e9,
+    )
+    sol.close()
+    return res, sysm
+
+
+def cpu_baseline(sysm, dt, budget_s=10.0):
+    """The C restatement (oracle/, test infrastructure) timed on the host as the reported CPU baseline."""
+    from oracle import c_oracle as co
+    S, C, K = sysm.S, sysm.C, sysm.K
+    best = None
+    for threads in sorted({1, min(co.max_threads(), os.cpu_count() or 1)}):
+        co.set_threads(threads)
+        co.linsys_solve(*sysm.csr_args(), S, C, K, 0.0, MAX_ITERS, sysm.rho, dtype=dt)   # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            co.linsys_solve(*sysm.csr_args(), S, C, K, 0.0, MAX_ITERS, sysm.rho, dtype=dt)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or n >= 20000:
+                break
+        v = MAX_ITERS * n / el
+        if best is None or v > best["value"]:
+            best = dict(value=v, unit="PCG iterations/s", cores=threads, kind="port",
+                        sample=f"{n} whole solves (assembly + {MAX_ITERS} PCG iterations + dz) of the same "
+                               f"{S}/{C}/{K} {dtype_name(dt)} system in {el:.1f} s, oracle/gato_oracle_impl.h")
+    return best
+
+
+def committed_traffic(name):
+    """HBM bytes per PCG launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get(name, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pcg-mode", type=int, default=None)
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from gato_python_amd import dist_bench
+        return dist_bench.main(args)
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(0)
+    name = args.workload or "iiwa_14_7_k50_f64"
+    S, C, K, dt, cfg = WORKLOADS[name]
+    res, sysm = run_single(name, args.steps, args.warmup, torch, args.pcg_mode)
+    out = {
+        "metric": "PCG iterations/s", "value": res["iters_per_s"], "unit": "iterations/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": res["dtype"], "data": "synthetic",
+        "config": {"workload": name, "baseline_config": cfg, "STATE_SIZE": S, "CONTROL_SIZE": C, "KNOT_POINTS": K,
+                   "max_iters": MAX_ITERS, "exit_tol": 0.0,
+                   "step": "convert + Schur/stair assembly + PCG(100 iterations) + dz, inputs resident in HBM",
+                   "pcg_kernel": res["pcg_mode"], "pcg_workgroups": res["pcg_groups"],
+                   "pcg_threads": res["pcg_threads"]},
+        "roofline": {"bound": "hbm", "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": committed_traffic(name),
+                     "kernel": "pcg_" + str(res["pcg_mode"]), "launch_ms": res["pcg_launch_ms"],
+                     "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_launch"],
+                     "pcg_only_iterations_per_s": res["pcg_iters_per_s"]},
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(sysm, dt)
+    if not args.no_sweep and args.workload is None:
+        sweep = []
+        for other in ("iiwa_14_7_k50_f32", "iiwa_14_7_k512_f32", "iiwa_14_7_k4096_f32", "iiwa_14_7_k4096_f64",
+                      "s32_c16_k1024_f32"):
+            r, _ = run_single(other, max(10, args.steps // 10), 3, torch)
+            r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
+            sweep.append(r)
+        out["sweep"] = sweep
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -23,7 +23,7 @@ SYMBOLS = [
     "gato_last_error", "gato_version", "gato_num_shapes", "gato_shape", "gato_device_info",
     "gato_infer_shape", "gato_solver_create", "gato_solver_destroy", "gato_solver_buffer",
     "gato_solver_set_option", "gato_solver_get_option", "gato_convert", "gato_form_schur",
-    "gato_form_ss", "gato_pcg", "gato_pcg_status", "gato_compute_dz", "gato_linsys_device",
+    "gato_form_ss", "gato_pcg", "gato_pcg_status", "gato_pcg_last_ms", "gato_compute_dz", "gato_linsys_device",
     "gato_linsys_solve_f32", "gato_linsys_solve_f64",
 ]
 
@@ -63,6 +63,7 @@ def lib() -> ct.CDLL:
         L.gato_form_ss.argtypes = [vp, vp, vp, vp]
         L.gato_pcg.argtypes = [vp, vp, vp, vp, vp, d, i, vp, vp]
         L.gato_pcg_status.argtypes = [vp, ct.POINTER(ct.c_int)]
+        L.gato_pcg_last_ms.argtypes = [vp, ct.POINTER(ct.c_float)]
         L.gato_compute_dz.argtypes = [vp] * 7
         L.gato_linsys_device.argtypes = [vp, ip, ip, vp, ip, ip, vp, vp, vp, d, i, d, vp, vp, vp]
         L.gato_infer_shape.argtypes = [ip, i, i, i] + [ct.POINTER(ct.c_int)] * 3

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, c
                 Sk[SS + i] = -sQik[i];                                       // :120-126
                 Pk[i] = (T)0;
                 Pk[SS + i] = -Gd[i];                                         // :75-81
-                if (K == 1) { Sk[2 * SS + i] = (T)0; Pk[2 * SS + i] = (T)0; }
+                Pk[2 * SS + i] = (T)0;
+                if (K == 1) Sk[2 * SS + i] = (T)0;
             }
             wave_sync();
             for (int i = lane; i < S; i += WAVE) gamma[i] = c[i] - sv[i];    // :131-146, + c_0 (D4)
@@ -215,7 +216,9 @@ __global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, c
             Sk[SS + i] = -th;                                                // S[k].main   :398-404
             const int r = i % S, cc = i / S;
             Sk[2 * SS + i - 3 * SS] = -sPhi[cc + r * S];                     // S[k-1].right = -phi^T  :443-455
-            if (k == K - 1) { Sk[2 * SS + i] = (T)0; Pk[2 * SS + i] = (T)0; } // last right: unused (:166-174)
+            Pk[i] = (T)0;                                                    // stair blocks come from form_ss
+            Pk[2 * SS + i] = (T)0;
+            if (k == K - 1) Sk[2 * SS + i] = (T)0;                           // last right: unused (:166-174)
         }
         wave_sync();
         gj_inverse<T, S>(sTh, sTmp, stmp, lane);                             // theta^-1    :407-414

@@ -98,6 +98,8 @@ struct gato_solver {
     char *in_arena;
     size_t in_bytes;
     int last_groups, last_threads, last_mode;
+    int time_pcg;
+    hipEvent_t ev_pcg0, ev_pcg1;
 };
 
 static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -245,6 +247,8 @@ extern "C" int gato_solver_destroy(gato_solver *s)
 {
     if (!s) return GATO_OK;
     hipSetDevice(s->device);
+    if (s->ev_pcg0) hipEventDestroy(s->ev_pcg0);
+    if (s->ev_pcg1) hipEventDestroy(s->ev_pcg1);
     if (s->arena) hipFree(s->arena);
     if (s->in_arena) hipFree(s->in_arena);
     delete s;
@@ -272,7 +276,22 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     if (!strcmp(name, "pcg_mode")) s->pcg_mode = value;
     else if (!strcmp(name, "pcg_threads")) s->pcg_threads = value;
     else if (!strcmp(name, "pcg_groups")) s->pcg_groups = value;
+    else if (!strcmp(name, "time_pcg")) {
+        s->time_pcg = value;
+        if (value && !s->ev_pcg0) {
+            GATO_HIP_CHECK(hipEventCreate(&s->ev_pcg0));
+            GATO_HIP_CHECK(hipEventCreate(&s->ev_pcg1));
+        }
+    }
     else { set_error("unknown option %s", name); return GATO_EINVAL; }
+    return GATO_OK;
+}
+
+extern "C" int gato_pcg_last_ms(gato_solver *s, float *ms)
+{
+    if (!s->time_pcg || !s->ev_pcg0) { set_error("pcg_last_ms: option time_pcg is off"); return GATO_EINVAL; }
+    GATO_HIP_CHECK(hipEventSynchronize(s->ev_pcg1));
+    GATO_HIP_CHECK(hipEventElapsedTime(ms, s->ev_pcg0, s->ev_pcg1));
     return GATO_OK;
 }
 
@@ -375,12 +394,17 @@ extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, con
         a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
         a.final_eta = s->final_eta;
         a.timeout_ticks = 200000000ull;   // 2 s at 100 MHz
+        a.ev_start = s->time_pcg ? s->ev_pcg0 : nullptr;
+        a.ev_stop = s->time_pcg ? s->ev_pcg1 : nullptr;
         s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT;
         return s->ops->pcg_resident(a, st);
     }
     s->last_mode = GATO_PCG_STREAMING; s->last_groups = 0; s->last_threads = 0;
-    return s->ops->pcg_streaming(s->d, d_S, d_Pinv, d_gamma, d_lambda, exit_tol, max_iters,
-                                 d_iters ? d_iters : s->iters, s->sw, st);
+    if (s->time_pcg) GATO_HIP_CHECK(hipEventRecord(s->ev_pcg0, st));
+    int rc = s->ops->pcg_streaming(s->d, d_S, d_Pinv, d_gamma, d_lambda, exit_tol, max_iters,
+                                   d_iters ? d_iters : s->iters, s->sw, st);
+    if (s->time_pcg) GATO_HIP_CHECK(hipEventRecord(s->ev_pcg1, st));
+    return rc;
 }
 
 extern "C" int gato_pcg_status(gato_solver *s, int *status)

@@ -57,6 +57,7 @@ struct PcgLaunch {
     int *status;                 // device, 0 ok / 1 timeout
     double *final_eta;           // device (optional)
     unsigned long long timeout_ticks;  // s_memrealtime ticks (100 MHz)
+    hipEvent_t ev_start, ev_stop;      // optional: recorded right around the kernel launch
 };
 
 // Granules (8 B: {epoch:32 | payload:32}) per workgroup and parity in the hand-off area.

@@ -341,8 +341,10 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
     const size_t slot_bytes = (size_t)2 * a.groups * pcg_slot_granules(S, (int)sizeof(T)) * 8;
     if (a.groups > 1) GATO_HIP_CHECK(hipMemsetAsync(a.slots, 0, slot_bytes, st));
     GATO_HIP_CHECK(hipMemsetAsync(a.status, 0, sizeof(int), st));
+    if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
     hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT>), dim3(a.groups), dim3(a.threads), 0, st, a);
     GATO_HIP_CHECK(hipGetLastError());
+    if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
     return GATO_OK;
 }
 

@@ -118,6 +118,12 @@ class Solver:
     def buffer_ptr(self, which: int) -> int:
         return int(_lib.lib().gato_solver_buffer(self._h, which))
 
+    def pcg_last_ms(self) -> float:
+        """Device time of the last PCG launch (needs set_option("time_pcg", 1))."""
+        ms = ct.c_float()
+        _lib.check(_lib.lib().gato_pcg_last_ms(self._h, ct.byref(ms)))
+        return ms.value
+
     def check_status(self):
         _lib.check(_lib.lib().gato_pcg_status(self._h, None))
 

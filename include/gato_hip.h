@@ -89,6 +89,10 @@ int gato_form_ss(gato_solver *s, const void *d_S, void *d_Pinv, void *stream);
 int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma,
              void *d_lambda, double exit_tol, int max_iters, int *d_iters, void *stream);
 int gato_pcg_status(gato_solver *s, int *status);
+/* Device time of the most recent PCG launch(es) of gato_pcg, measured with hipEvents recorded on the
+ * launch stream immediately around the kernel launch(es) (the reference times whole solves with
+ * cudaEvents, gpu_library.cu:167-187).  Enabled by option "time_pcg" = 1; synchronises on the stop event. */
+int gato_pcg_last_ms(gato_solver *s, float *ms);
 /* A9  compute_dz (gato_schur.cuh:1012-1022) with d_Ginv_dense = inverses from gato_form_schur. */
 int gato_compute_dz(gato_solver *s, const void *d_Ginv_dense, const void *d_C_dense, const void *d_g,
                     const void *d_lambda, void *d_dz, void *stream);

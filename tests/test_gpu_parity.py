@@ -227,7 +227,8 @@ def test_full_size_properties(S, C, K, dt):
     r2 = Cm @ d - s.c
     scale = max(np.abs(s.g).max(), np.abs(l).max())
     assert np.abs(r1).max() / scale < (1e-10 if f64 else 1e-4)
-    assert np.abs(r2).max() < (1e-6 if f64 else 5e-2)
+    # the constraint residual is the Schur-system residual left by the exit test |r.Pinv r| < tol
+    assert np.abs(r2).max() / max(np.abs(d).max(), 1.0) < (5e-6 if f64 else 1e-3)
     lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
     assert rel(l, lam_o) < (1e-8 if f64 else 2e-2)
     # streaming variant gives the same answer

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun):  bash tools/profile.sh [tag]
+# Produces gpurun_out/prof_<tag>_{stats,fetch,write}/ ; summarise with tools/summarize_profile.py
+# and copy the summaries into profiles/.  Counters are collected in their own passes
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950), never together with API tracing.
+set -o pipefail
+TAG=${1:-r01}
+R=$PWD
+ARGS=${BENCH_ARGS:---steps 50 --warmup 5 --no-cpu}
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_stats -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_bench.json 2> $R/gpurun_out/prof_${TAG}_stats.err || exit 1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_fetch -- python3 $R/bench.py $ARGS > /dev/null 2> $R/gpurun_out/prof_${TAG}_fetch.err || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_write -- python3 $R/bench.py $ARGS > /dev/null 2> $R/gpurun_out/prof_${TAG}_write.err || exit 1
+echo profile $TAG done

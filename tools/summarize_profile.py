@@ -1,0 +1,77 @@
+"""Summarise gpurun_out/prof_<tag>_{stats,fetch,write} into profiles/ (tracked):
+  profiles/<tag>_kernel_stats.csv  - rocprofv3 --kernel-trace --stats summary, verbatim
+  profiles/<tag>_pcg_launches.csv  - per (kernel, grid) launch durations of the PCG kernels from the trace
+  profiles/pmc_traffic.json        - HBM bytes per PCG launch per bench workload from the PMC passes
+    python tools/summarize_profile.py r01
+"""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
+    return g[0] if g else None
+
+
+stats = one(f"prof_{tag}_stats/*/*_kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
+trace = one(f"prof_{tag}_stats/*/*_kernel_trace.csv")
+launch = defaultdict(list)
+if trace:
+    for r in csv.DictReader(open(trace)):
+        if "pcg_" in r["Kernel_Name"] or "stream_step" in r["Kernel_Name"]:
+            key = (r["Kernel_Name"].split("(")[0].replace("void gato::(anonymous namespace)::", ""),
+                   int(r["Grid_Size_X"] if "Grid_Size_X" in r else r["Grid_Size"]),
+                   int(r["Workgroup_Size_X"] if "Workgroup_Size_X" in r else r["Workgroup_Size"]))
+            launch[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(out, f"{tag}_pcg_launches.csv"), "w") as f:
+        f.write("kernel,grid_threads,workgroup_threads,launches,avg_ns,min_ns,max_ns\n")
+        for k, v in sorted(launch.items()):
+            f.write(f'"{k[0]}",{k[1]},{k[2]},{len(v)},{sum(v) / len(v):.0f},{min(v)},{max(v)}\n')
+
+
+def counter(kind):
+    p = one(f"prof_{tag}_{kind}/*/*_counter_collection.csv")
+    acc = defaultdict(list)
+    if p:
+        for r in csv.DictReader(open(p)):
+            if "pcg_" in r["Kernel_Name"] or "stream_step" in r["Kernel_Name"]:
+                key = (r["Kernel_Name"].split("(")[0].replace("void gato::(anonymous namespace)::", ""),
+                       int(r["Grid_Size"]), int(r["Workgroup_Size"]))
+                acc[key].append(float(r["Counter_Value"]))
+    return acc
+
+
+fetch, write = counter("fetch"), counter("write")
+# bench workloads -> (kernel template prefix, S, dtype) ; grid identifies K
+WL = {"iiwa_14_7_k50_f64": ("pcg_resident_kernel<double, 14", 50), "iiwa_14_7_k50_f32": ("pcg_resident_kernel<float, 14", 50),
+      "iiwa_14_7_k512_f32": ("pcg_resident_kernel<float, 14", 512), "iiwa_14_7_k4096_f32": ("pcg_resident_kernel<float, 14", 4096),
+      "iiwa_14_7_k4096_f64": ("pcg_resident_kernel<double, 14", 4096), "s32_c16_k1024_f32": ("pcg_resident_kernel<float, 32", 1024)}
+bench = one(f"prof_{tag}_bench.json")
+geom = {}
+if bench:
+    try:
+        d = json.loads(open(bench).read().strip().splitlines()[-1])
+        geom[d["config"]["workload"]] = d["config"]["pcg_workgroups"] * d["config"]["pcg_threads"]
+        for r in d.get("sweep", []):
+            geom[r["workload"]] = r["pcg_groups"] * r["pcg_threads"]
+    except Exception as e:
+        print("bench json unreadable:", e)
+traffic = {}
+for name, (prefix, K) in WL.items():
+    for key in fetch:
+        if key[0].startswith(prefix) and geom.get(name) == key[1]:
+            f_kb = sum(fetch[key]) / len(fetch[key])
+            w_kb = sum(write[key]) / len(write[key]) if key in write else 0.0
+            traffic[name] = dict(kernel=key[0], grid_threads=key[1], fetch_size_kb=f_kb, write_size_kb=w_kb,
+                                 hbm_bytes_per_launch=(f_kb + w_kb) * 1024,
+                                 note="FETCH_SIZE taken as reported (narrow 4/8-byte loads: the x2 correction of "
+                                      "MI355X_MICROARCH.md applies to 16-B-per-lane streams only); launches=%d" % len(fetch[key]))
+json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print("wrote", sorted(os.listdir(out)))
