@@ -25,6 +25,7 @@ SYMBOLS = [
     "gato_solver_set_option", "gato_solver_get_option", "gato_convert", "gato_form_schur",
     "gato_form_ss", "gato_pcg", "gato_pcg_status", "gato_pcg_last_ms", "gato_compute_dz", "gato_linsys_device",
     "gato_linsys_solve_f32", "gato_linsys_solve_f64",
+    "gato_shard_pcg_init", "gato_shard_pcg_phase_a", "gato_shard_pcg_phase_b", "gato_shard_pcg_finish",
 ]
 
 
@@ -68,6 +69,10 @@ def lib() -> ct.CDLL:
         L.gato_linsys_device.argtypes = [vp, ip, ip, vp, ip, ip, vp, vp, vp, d, i, d, vp, vp, vp]
         L.gato_infer_shape.argtypes = [ip, i, i, i] + [ct.POINTER(ct.c_int)] * 3
         L.gato_device_info.argtypes = [i, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int), ct.c_char_p, i]
+        L.gato_shard_pcg_init.argtypes = [vp, i, i, i, i, vp, vp, vp, d, i, vp, vp]
+        L.gato_shard_pcg_phase_a.argtypes = [vp, i, vp, vp, vp, vp]
+        L.gato_shard_pcg_phase_b.argtypes = [vp, i, vp, vp, vp, vp]
+        L.gato_shard_pcg_finish.argtypes = [vp, vp, vp, vp, vp]
         f = ct.c_float
         L.gato_linsys_solve_f32.argtypes = [ip, i, ip, vp, i, ip, i, ip, vp, i, vp, i, vp, i, vp,
                                             i, i, i, i, f, i, i, f, vp, vp, vp, vp]

@@ -43,6 +43,15 @@ static Ops make_ops(int dtype)
     };
     o.pcg_plan = [](PcgPlan *p) { return pcg_resident_plan<T, S>(p); };
     o.pcg_resident = [](const PcgLaunch &a, hipStream_t st) { return launch_pcg_resident<T, S>(a, st); };
+    o.stream_grid = [](int K, int mg) { return stream_grid<T, S>(K, mg); };
+    o.stream_step = [](int ph, const StreamStep &a, int grid, hipStream_t st) { return launch_stream_step<T, S>(ph, a, grid, st); };
+    o.stream_pack = [](const void *sl, int n, const void *y, int K, void *send, hipStream_t st) {
+        return launch_stream_pack<T, S>(sl, n, y, K, send, st);
+    };
+    o.stream_finish = [](const void *part, int n, int stride, double tol, int last_it, int *done, int *iters,
+                         double *fe, hipStream_t st) {
+        return launch_stream_finish<T, S>(part, n, stride, tol, last_it, done, iters, fe, st);
+    };
     o.pcg_streaming = [](const Dims &d, const void *Sb, const void *Pb, const void *gam, void *lam, double tol,
                          int max_iters, int *iters, const PcgStreamWork &w, hipStream_t st) {
         return launch_pcg_streaming<T, S>(d, (const T *)Sb, (const T *)Pb, (const T *)gam, (T *)lam, (T)tol,
@@ -100,6 +109,13 @@ struct gato_solver {
     int last_groups, last_threads, last_mode;
     int time_pcg;
     hipEvent_t ev_pcg0, ev_pcg1;
+    // knot-sharded PCG state (gato_shard_pcg_*)
+    struct {
+        int rank, nranks, k0, k1, grid, max_iters;
+        double exit_tol;
+        const char *S_full, *P_full, *gamma_full;
+    } sh;
+    char *ghosts;   // [r|p][ping-pong][left|right][S]
 };
 
 static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -226,6 +242,7 @@ extern "C" int gato_solver_create(int S, int C, int K, int dtype, int device, ga
     const size_t o_lam = take(d.sk() * e), o_dz = take(d.N() * e);
     const size_t o_vec = take(6 * d.sk() * e);
     const size_t o_part = take((size_t)4 * max_groups * e), o_scal = take(64 * 8), o_done = take(64);
+    const size_t o_gh = take((size_t)8 * S * e);
     s->arena_bytes = off;
     GATO_HIP_CHECK(hipMalloc((void **)&s->arena, off));
     GATO_HIP_CHECK(hipMemset(s->arena, 0, off));
@@ -239,6 +256,7 @@ extern "C" int gato_solver_create(int S, int C, int K, int dtype, int device, ga
     s->sw.vecs = a + o_vec;
     s->sw.partials = a + o_part; s->sw.scalars = a + o_scal; s->sw.done = (int *)(a + o_done);
     s->sw.max_groups = max_groups;
+    s->ghosts = a + o_gh;
     *out = s;
     return GATO_OK;
 }
@@ -533,4 +551,126 @@ extern "C" int gato_linsys_solve_f64(const int *G_row, int len_G_row, const int 
     return linsys_solve_host<double>(GATO_F64, G_row, len_G_row, G_col, G_val, nnz_G, C_row, len_C_row, C_col, C_val,
                                      nnz_C, g, len_g, c, len_c, lambda_in, S, C, K, testiters, exit_tol, max_iters,
                                      warm_start, rho, lambda_out, dz_out, iters_out, ms_out);
+}
+
+// ---- knot-sharded PCG (multi-GPU) ------------------------------------------------------------------
+static char *ghost_ptr(gato_solver *s, int vec /*0 r, 1 p*/, int pp, int side)
+{
+    return s->ghosts + ((size_t)((vec * 2 + pp) * 2 + side) * s->d.S) * s->esz;
+}
+
+static void shard_vectors(gato_solver *s, char *r[2], char *p[2], char **ups, char **rt)
+{
+    const size_t sk = s->d.sk() * s->esz;
+    char *v = (char *)s->sw.vecs;
+    r[0] = v; r[1] = v + sk; p[0] = v + 2 * sk; p[1] = v + 3 * sk; *ups = v + 4 * sk; *rt = v + 5 * sk;
+}
+
+static void shard_common(gato_solver *s, StreamStep &a)
+{
+    memset(&a, 0, sizeof(a));
+    a.K = s->sh.k1 - s->sh.k0;
+    a.max_iters = s->sh.max_iters; a.exit_tol = s->sh.exit_tol; a.done = s->sw.done; a.iters = s->iters;
+    a.first_global = s->sh.k0 == 0; a.last_global = s->sh.k1 == s->d.K;
+}
+
+extern "C" int gato_shard_pcg_init(gato_solver *s, int rank, int nranks, int k0, int k1, const void *d_S,
+                                   const void *d_Pinv, const void *d_gamma, double exit_tol, int max_iters,
+                                   void *d_send, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int S = s->d.S;
+    const size_t e = s->esz;
+    if (rank < 0 || rank >= nranks || k0 < 0 || k1 <= k0 || k1 > s->d.K || (rank == 0) != (k0 == 0) ||
+        (rank == nranks - 1) != (k1 == s->d.K)) {
+        set_error("shard_pcg_init: bad shard rank=%d/%d knots [%d,%d) of %d", rank, nranks, k0, k1, s->d.K);
+        return GATO_EINVAL;
+    }
+    s->sh.rank = rank; s->sh.nranks = nranks; s->sh.k0 = k0; s->sh.k1 = k1; s->sh.max_iters = max_iters;
+    s->sh.exit_tol = exit_tol;
+    s->sh.S_full = (const char *)d_S; s->sh.P_full = (const char *)d_Pinv; s->sh.gamma_full = (const char *)d_gamma;
+    s->sh.grid = s->ops->stream_grid(k1 - k0, s->sw.max_groups);
+    GATO_HIP_CHECK(hipMemsetAsync(s->lambda, 0, s->d.sk() * e, st));
+    char *r[2], *p[2], *ups, *rt;
+    shard_vectors(s, r, p, &ups, &rt);
+    StreamStep a;
+    shard_common(s, a);
+    a.M = s->sh.P_full + (size_t)k0 * 3 * S * S * e;
+    a.a_old = s->sh.gamma_full + (size_t)k0 * S * e;
+    a.gh_a_left = s->sh.gamma_full + (size_t)(k0 > 0 ? k0 - 1 : 0) * S * e;
+    a.gh_a_right = s->sh.gamma_full + (size_t)(k1 < s->d.K ? k1 : 0) * S * e;
+    a.gh_new_left = ghost_ptr(s, 0, 0, 0); a.gh_new_right = ghost_ptr(s, 0, 0, 1);
+    a.a_new = r[0]; a.y = rt; a.lam = (char *)s->lambda + (size_t)k0 * S * e;
+    a.part_out = s->sw.partials; a.it = 0;
+    int rc;
+    if ((rc = s->ops->stream_step(0, a, s->sh.grid, st))) return rc;
+    return s->ops->stream_pack(s->sw.partials, s->sh.grid, rt, k1 - k0, d_send, st);
+}
+
+extern "C" int gato_shard_pcg_phase_a(gato_solver *s, int it, const void *d_recvB_cur, const void *d_recvB_prev,
+                                      void *d_send, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int S = s->d.S, REC = 2 * S + 1, rank = s->sh.rank;
+    const size_t e = s->esz;
+    char *r[2], *p[2], *ups, *rt;
+    shard_vectors(s, r, p, &ups, &rt);
+    const int pi = it & 1;
+    StreamStep a;
+    shard_common(s, a);
+    a.M = s->sh.S_full + (size_t)s->sh.k0 * 3 * S * S * e;
+    a.a_old = p[pi ^ 1]; a.b = rt; a.a_new = p[pi]; a.y = ups; a.it = it;
+    a.part_num = d_recvB_cur; a.num_n = s->sh.nranks; a.num_stride = REC;
+    a.part_den = d_recvB_prev; a.den_n = s->sh.nranks; a.den_stride = REC;
+    const char *rb = (const char *)d_recvB_cur;                 // r~ blocks of the neighbours
+    a.gh_b_left = rb + ((size_t)(rank > 0 ? rank - 1 : 0) * REC + 1 + S) * e;
+    a.gh_b_right = rb + ((size_t)(rank + 1 < s->sh.nranks ? rank + 1 : 0) * REC + 1) * e;
+    a.gh_a_left = ghost_ptr(s, 1, pi ^ 1, 0); a.gh_a_right = ghost_ptr(s, 1, pi ^ 1, 1);
+    a.gh_new_left = ghost_ptr(s, 1, pi, 0); a.gh_new_right = ghost_ptr(s, 1, pi, 1);
+    char *PA = (char *)s->sw.partials + (size_t)3 * s->sw.max_groups * e;
+    a.part_out = PA;
+    int rc;
+    if ((rc = s->ops->stream_step(1, a, s->sh.grid, st))) return rc;
+    return s->ops->stream_pack(PA, s->sh.grid, ups, s->sh.k1 - s->sh.k0, d_send, st);
+}
+
+extern "C" int gato_shard_pcg_phase_b(gato_solver *s, int it, const void *d_recvB_cur, const void *d_recvA,
+                                      void *d_send, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int S = s->d.S, REC = 2 * S + 1, rank = s->sh.rank;
+    const size_t e = s->esz;
+    char *r[2], *p[2], *ups, *rt;
+    shard_vectors(s, r, p, &ups, &rt);
+    const int ri = it & 1, pi = it & 1;
+    StreamStep a;
+    shard_common(s, a);
+    a.M = s->sh.P_full + (size_t)s->sh.k0 * 3 * S * S * e;
+    a.a_old = r[ri]; a.b = ups; a.a_new = r[ri ^ 1]; a.y = rt; a.it = it;
+    a.lam = (char *)s->lambda + (size_t)s->sh.k0 * S * e; a.p_cur = p[pi];
+    a.part_num = d_recvB_cur; a.num_n = s->sh.nranks; a.num_stride = REC;   // eta(it)
+    a.part_den = d_recvA; a.den_n = s->sh.nranks; a.den_stride = REC;       // v(it)
+    const char *ra = (const char *)d_recvA;                     // upsilon blocks of the neighbours
+    a.gh_b_left = ra + ((size_t)(rank > 0 ? rank - 1 : 0) * REC + 1 + S) * e;
+    a.gh_b_right = ra + ((size_t)(rank + 1 < s->sh.nranks ? rank + 1 : 0) * REC + 1) * e;
+    a.gh_a_left = ghost_ptr(s, 0, ri, 0); a.gh_a_right = ghost_ptr(s, 0, ri, 1);
+    a.gh_new_left = ghost_ptr(s, 0, ri ^ 1, 0); a.gh_new_right = ghost_ptr(s, 0, ri ^ 1, 1);
+    a.part_out = s->sw.partials;
+    int rc;
+    if ((rc = s->ops->stream_step(2, a, s->sh.grid, st))) return rc;
+    return s->ops->stream_pack(s->sw.partials, s->sh.grid, rt, s->sh.k1 - s->sh.k0, d_send, st);
+}
+
+extern "C" int gato_shard_pcg_finish(gato_solver *s, const void *d_recvB_last, void *d_lambda_full_out, int *d_iters,
+                                     void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    int rc = s->ops->stream_finish(d_recvB_last, s->sh.nranks, 2 * s->d.S + 1, s->sh.exit_tol, s->sh.max_iters - 1,
+                                   s->sw.done, s->iters, s->final_eta, st);
+    if (rc) return rc;
+    if (d_lambda_full_out && d_lambda_full_out != s->lambda)
+        GATO_HIP_CHECK(hipMemcpyAsync(d_lambda_full_out, s->lambda, s->d.sk() * s->esz, hipMemcpyDeviceToDevice, st));
+    if (d_iters && d_iters != s->iters)
+        GATO_HIP_CHECK(hipMemcpyAsync(d_iters, s->iters, sizeof(int), hipMemcpyDeviceToDevice, st));
+    return GATO_OK;
 }

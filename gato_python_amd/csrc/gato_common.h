@@ -99,6 +99,38 @@ struct PcgStreamWork {
     int *done;                     // device flag
     int max_groups;
 };
+// One launch of the streaming PCG on a shard of block rows (see gato_pcg_stream.hip).
+struct StreamStep {
+    const void *M;          // S_bd (phase A) or Pinv_bd (phase B), local block rows
+    const void *a_old;      // p_old (A) / r_old (B) / gamma (init)
+    const void *b;          // r~ (A) / upsilon (B)
+    void *a_new;            // p_new (A) / r_new (B)
+    void *y;                // upsilon (A) / r~ (B)
+    void *lam;              // B and init
+    const void *p_cur;      // B only: p of this iteration
+    const void *part_num;   // coefficient = sum(num)/sum(den): partial arrays with element stride
+    const void *part_den;
+    int num_n, num_stride, den_n, den_stride;
+    void *part_out;         // one slot per workgroup
+    // ghosts of the neighbouring shards (multi-GPU): S-blocks of a_old and b, and where the advanced ghost goes
+    const void *gh_a_left, *gh_a_right, *gh_b_left, *gh_b_right;
+    void *gh_new_left, *gh_new_right;
+    int first_global, last_global;
+    int K;                  // local knots
+    int it;
+    int max_iters;
+    double exit_tol;
+    int *done;
+    int *iters;
+};
+template <typename T, int S> int stream_grid(int K, int max_groups);
+template <typename T, int S> int launch_stream_step(int phase, const StreamStep &a, int grid, hipStream_t st);
+template <typename T, int S>
+int launch_stream_pack(const void *slots, int nslots, const void *y, int K, void *send, hipStream_t st);
+template <typename T, int S>
+int launch_stream_finish(const void *part, int n, int stride, double exit_tol, int last_it, int *done, int *iters,
+                         double *final_eta, hipStream_t st);
+
 template <typename T, int S>
 int launch_pcg_streaming(const Dims &d, const T *Sbd, const T *Pbd, const T *gamma, T *lambda,
                          T exit_tol, int max_iters, int *iters, const PcgStreamWork &w, hipStream_t st);
@@ -117,6 +149,10 @@ struct Ops {
     int (*pcg_resident)(const PcgLaunch &, hipStream_t);
     int (*pcg_streaming)(const Dims &, const void *, const void *, const void *, void *, double, int, int *,
                          const PcgStreamWork &, hipStream_t);
+    int (*stream_grid)(int, int);
+    int (*stream_step)(int, const StreamStep &, int, hipStream_t);
+    int (*stream_pack)(const void *, int, const void *, int, void *, hipStream_t);
+    int (*stream_finish)(const void *, int, int, double, int, int *, int *, double *, hipStream_t);
 };
 const Ops *find_ops(int S, int C, int dtype);
 

@@ -1,0 +1,173 @@
+"""Knot-sharded PCG across the GPUs of one node (new work - the reference is
+single-device, src/gato_utils.cuh:831, and has no communication layer).
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU
+tests).  Rank r owns a contiguous range of block rows of S / Pinv.  Per PCG iteration there are exactly
+two collectives, each ONE all-gather of a fixed-size record per rank
+
+      record = [ partial dot | first S-block | last S-block ]   (2S+1 scalars)
+
+of the vector the rank just produced (upsilon after S.p, r~ after Pinv.r).  The gathered array gives
+every rank the global dot (summed in rank order on the device: bitwise identical everywhere, so every
+rank takes the same exit decision) and its two neighbours' boundary blocks; ghost blocks of r and p are
+advanced locally (ghost_r -= alpha ghost_upsilon ; ghost_p = ghost_r~ + beta ghost_p).  Nothing on the
+host reads device data inside the loop: kernels and collectives are only enqueued.
+
+ShardedPCG is the orchestration; the arithmetic lives behind a backend object (HipShardBackend: the HIP
+kernels through the C ABI, gato_shard_pcg_* in include/gato_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes as ct
+
+import numpy as np
+
+
+def knot_ranges(K: int, nranks: int):
+    """Balanced contiguous ranges [k0,k1) in rank order; every rank owns at least one knot."""
+    if nranks > K:
+        raise ValueError(f"cannot shard {K} knots over {nranks} ranks")
+    base, extra = divmod(K, nranks)
+    out, k = [], 0
+    for r in range(nranks):
+        n = base + (1 if r < extra else 0)
+        out.append((k, k + n))
+        k += n
+    return out
+
+
+class ShardedPCG:
+    """Collective schedule of the sharded PCG.  backend must provide
+         new_record() / new_gathered()                      buffers for all_gather_into_tensor
+         init(send) ; phase_a(it, recvB_cur, recvB_prev, send) ; phase_b(it, recvB_cur, recvA, send)
+         finish(recvB_last) -> (lambda_full_masked, iters)  tensors
+         done() -> bool                                     (only used when check_every > 0)
+    """
+
+    def __init__(self, backend, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.backend = backend
+        self.group = group
+
+    def _gather(self, out, send):
+        self.dist.all_gather_into_tensor(out, send, group=self.group)
+
+    def solve(self, max_iters: int, check_every: int = 0):
+        b = self.backend
+        send = b.new_record()
+        recvB = [b.new_gathered() for _ in range(3)]
+        recvA = b.new_gathered()
+        b.init(send)
+        self._gather(recvB[0], send)
+        for it in range(max_iters):
+            b.phase_a(it, recvB[it % 3], recvB[(it + 2) % 3], send)
+            self._gather(recvA, send)
+            b.phase_b(it, recvB[it % 3], recvA, send)
+            self._gather(recvB[(it + 1) % 3], send)
+            if check_every and (it + 1) % check_every == 0 and b.done():
+                break          # every rank sees the same flag: the sums are identical on all ranks
+        lam, iters = b.finish(recvB[max_iters % 3])
+        self.dist.all_reduce(lam, op=self.dist.ReduceOp.SUM, group=self.group)   # slices are disjoint, rest is 0
+        return lam, iters
+
+
+def run_lockstep(backends, max_iters: int):
+    """The same schedule for a list of backends living in ONE process (rank i = backends[i]): the
+    all-gather becomes a concatenation.  Used to exercise the shard kernels on a single GPU."""
+    import torch
+    n = len(backends)
+    send = [b.new_record() for b in backends]
+    cat = lambda: torch.cat(send)
+    backends[0].torch = torch
+    for b, s_ in zip(backends, send):
+        b.init(s_)
+    recvB = [None, None, None]
+    recvB[0] = cat()
+    recvA = None
+    for it in range(max_iters):
+        prev = recvB[(it + 2) % 3] if recvB[(it + 2) % 3] is not None else recvB[it % 3]
+        for b, s_ in zip(backends, send):
+            b.phase_a(it, recvB[it % 3], prev, s_)
+        recvA = cat()
+        for b, s_ in zip(backends, send):
+            b.phase_b(it, recvB[it % 3], recvA, s_)
+        recvB[(it + 1) % 3] = cat()
+    outs = [b.finish(recvB[max_iters % 3]) for b in backends]
+    lam = outs[0][0].clone()
+    for o_ in outs[1:]:
+        lam += o_[0]
+    return lam, [o_[1] for o_ in outs]
+
+
+class HipShardBackend:
+    """The HIP kernels behind ShardedPCG: streaming PCG step on this rank's shard (C ABI)."""
+
+    def __init__(self, solver, rank, nranks, d_S, d_Pinv, d_gamma, exit_tol, max_iters):
+        import torch
+        from . import _lib
+        self.torch, self._lib, self.sol = torch, _lib, solver
+        self.rank, self.nranks = rank, nranks
+        self.k0, self.k1 = knot_ranges(solver.K, nranks)[rank]
+        self.S_bd, self.P_bd, self.gamma = d_S, d_Pinv, d_gamma
+        self.exit_tol, self.max_iters = float(exit_tol), int(max_iters)
+        self.rec = 2 * solver.S + 1
+
+    def _st(self):
+        return self.sol._stream()
+
+    def new_record(self):
+        return self.sol.new(self.rec)
+
+    def new_gathered(self):
+        return self.sol.new(self.rec * self.nranks)
+
+    @staticmethod
+    def _p(t):
+        return ct.c_void_p(t.data_ptr())
+
+    def init(self, send):
+        L = self._lib.lib()
+        self._lib.check(L.gato_shard_pcg_init(self.sol._h, self.rank, self.nranks, self.k0, self.k1, self._p(self.S_bd),
+                                              self._p(self.P_bd), self._p(self.gamma), self.exit_tol,
+                                              self.max_iters, self._p(send), self._st()))
+
+    def phase_a(self, it, recvB_cur, recvB_prev, send):
+        self._lib.check(self._lib.lib().gato_shard_pcg_phase_a(self.sol._h, it, self._p(recvB_cur), self._p(recvB_prev),
+                                                               self._p(send), self._st()))
+
+    def phase_b(self, it, recvB_cur, recvA, send):
+        self._lib.check(self._lib.lib().gato_shard_pcg_phase_b(self.sol._h, it, self._p(recvB_cur), self._p(recvA),
+                                                               self._p(send), self._st()))
+
+    def finish(self, recvB_last):
+        lam = self.sol.new(self.sol.S * self.sol.K)
+        iters = self.sol.new(1, self.torch.int32)
+        self._lib.check(self._lib.lib().gato_shard_pcg_finish(self.sol._h, self._p(recvB_last), self._p(lam),
+                                                              self._p(iters), self._st()))
+        return lam, iters
+
+    def done(self):
+        raise NotImplementedError("host-side convergence polling is not wired for the HIP backend yet")
+
+
+def linsys_solve_sharded(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None):
+    """Whole solve with the PCG sharded over the ranks of `group`.  Assembly (CSR scatter, Schur, stair)
+    is replicated on every rank from the replicated CSR inputs - it is a one-off O(K) step and replication
+    needs no exchange (SURVEY.md section 8e lists the halo terms it would otherwise need) - then the PCG
+    runs on each rank's knot range and lambda is assembled by a sum-all-reduce of the disjoint slices; dz
+    is computed redundantly on every rank.  Returns (lambda, dz, iters) as device tensors."""
+    import torch
+    import torch.distributed as dist
+    from .solver import Solver
+    rank, nranks = dist.get_rank(group), dist.get_world_size(group)
+    dev = torch.cuda.current_device() if device is None else device
+    sol = Solver(sysm.S, sysm.C, sysm.K, dtype, dev)
+    d = sol.upload_system(sysm)
+    Gd, Cd = sol.convert(*d[:6], sysm.rho)
+    Sb, Pb, gam, Gi = sol.form_schur(Gd, Cd, d[6], d[7])
+    sol.form_ss(Sb, Pb)
+    backend = HipShardBackend(sol, rank, nranks, Sb, Pb, gam, exit_tol, max_iters)
+    lam, iters = ShardedPCG(backend, group).solve(max_iters)
+    dz = sol.compute_dz(Gi, Cd, d[6], lam)
+    return lam, dz, iters, sol

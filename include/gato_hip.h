@@ -123,6 +123,33 @@ int gato_linsys_solve_f64(const int *G_row, int len_G_row, const int *G_col, con
                           int warm_start, double rho, double *lambda_out, double *dz_out,
                           int *iters_out, float *ms_out);
 
+/* ---- knot-sharded PCG across GPUs (NEW work: the reference is single-device, gato_utils.cuh:831,
+ * and has no communication library).  One process per GPU; rank r owns block
+ * rows [k0,k1) of S / Pinv (contiguous, in rank order) and keeps the full gamma.  Per PCG iteration each
+ * rank runs two launches of the streaming kernel on its shard and exchanges one fixed-size RECORD after
+ * each:  record = [partial dot | first S-block | last S-block] of the vector just produced (2S+1
+ * elements of the solver dtype).  The caller all-gathers the records of all ranks (RCCL
+ * all_gather over xGMI; gloo in the CPU tests) and hands the gathered array [nranks][2S+1] to the next
+ * call - that one collective carries both the global dot (summed in rank order: deterministic) and the
+ * neighbour halos.  Ghost blocks of r and p are advanced locally from the neighbours' upsilon / r~
+ * blocks, so there are exactly two collectives per iteration and no host synchronisation.
+ *   init    : r = gamma, lambda = 0, r~ = Pinv r                       -> send = record(r.r~ , r~)
+ *   phase_a : p = r~ + beta p, upsilon = S p      (needs gathered B records of it-1 and it-2 / init)
+ *                                                                      -> send = record(p.upsilon, upsilon)
+ *   phase_b : lambda += alpha p, r -= alpha upsilon, r~ = Pinv r  (needs gathered B record of it-1 / init
+ *             and the gathered A record of this iteration)              -> send = record(r.r~, r~)
+ *   finish  : last exit test; d_lambda_full_out (S*K_total) = own slice of lambda, zero elsewhere
+ *             (sum-all-reduce it to assemble lambda); d_iters as gato_pcg.
+ * S/Pinv/gamma pointers are FULL-system arrays (block row 0 first); all pointers are device pointers. */
+int gato_shard_pcg_init(gato_solver *s, int rank, int nranks, int k0, int k1, const void *d_S, const void *d_Pinv,
+                        const void *d_gamma, double exit_tol, int max_iters, void *d_send, void *stream);
+int gato_shard_pcg_phase_a(gato_solver *s, int it, const void *d_recvB_cur, const void *d_recvB_prev, void *d_send,
+                           void *stream);
+int gato_shard_pcg_phase_b(gato_solver *s, int it, const void *d_recvB_cur, const void *d_recvA, void *d_send,
+                           void *stream);
+int gato_shard_pcg_finish(gato_solver *s, const void *d_recvB_last, void *d_lambda_full_out, int *d_iters,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

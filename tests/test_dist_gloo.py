@@ -1,0 +1,39 @@
+"""CPU suite: the knot-sharded PCG schedule (gato_python_amd/dist.py) on gloo worlds of 2 and 3 ranks.
+The arithmetic behind the schedule is the test-only numpy backend (tests/shard_numpy_backend.py); the
+result must equal the single-process oracle PCG: same iteration count, lambda to 1e-10."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from gato_python_amd.dist import knot_ranges
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,S,C,K,tol,mi,chk", [(2, 14, 7, 11, 1e-10, 200, 0), (3, 2, 1, 8, 1e-12, 100, 0),
+                                                    (2, 2, 1, 2, 1e-12, 50, 0), (2, 14, 7, 16, 0.0, 7, 0),
+                                                    (2, 14, 7, 11, 1e-10, 200, 4)])
+def test_sharded_pcg_gloo(world, S, C, K, tol, mi, chk):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(S), str(C), str(K), str(tol), str(mi), str(chk)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count(" ok iters=") == world
+
+
+def test_knot_ranges():
+    assert knot_ranges(4096, 8) == [(i * 512, (i + 1) * 512) for i in range(8)]
+    assert knot_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    with pytest.raises(ValueError):
+        knot_ranges(2, 3)
