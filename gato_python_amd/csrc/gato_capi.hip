@@ -107,7 +107,7 @@ struct gato_solver {
     char *in_arena;
     size_t in_bytes;
     int last_groups, last_threads, last_mode;
-    int time_pcg;
+    int time_pcg, stamp_pcg, ablate;
     hipEvent_t ev_pcg0, ev_pcg1;
     // knot-sharded PCG state (gato_shard_pcg_*)
     struct {
@@ -285,6 +285,7 @@ extern "C" void *gato_solver_buffer(gato_solver *s, int which)
         case 6: return s->lambda;
         case 7: return s->dz;
         case 8: return s->iters;
+        case 9: return (unsigned long long *)s->sw.scalars + 8;   // diagnostic stamps (option stamp_pcg)
         default: return nullptr;
     }
 }
@@ -294,6 +295,8 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     if (!strcmp(name, "pcg_mode")) s->pcg_mode = value;
     else if (!strcmp(name, "pcg_threads")) s->pcg_threads = value;
     else if (!strcmp(name, "pcg_groups")) s->pcg_groups = value;
+    else if (!strcmp(name, "stamp_pcg")) s->stamp_pcg = value;
+    else if (!strcmp(name, "ablate")) s->ablate = value;
     else if (!strcmp(name, "time_pcg")) {
         s->time_pcg = value;
         if (value && !s->ev_pcg0) {
@@ -370,13 +373,14 @@ static int plan_resident(gato_solver *s, int *groups, int *threads, int *kpw)
         if (t > maxT) return 0;
     }
     if (t == 0) {
-        // auto: one workgroup while the problem fits one CU's registers (no inter-CU traffic);
-        // otherwise the fewest waves per SIMD that still fits the chip.
+        // auto: one workgroup while the problem fits one CU's registers (no inter-CU traffic at all);
+        // otherwise 512-thread workgroups (measured best on MI355X: 2 waves per SIMD hide the LDS latency
+        // of the operand window, and W stays small enough that one wave sweeps all partial granules),
+        // growing only if that would need more workgroups than CUs.
         if (K * S <= maxT) t = (K * S + 63) / 64 * 64;
         else {
-            t = 256;
-            while (t < maxT && (long long)((K + (t / S) - 1) / (t / S)) > max_wg) t *= 2;
-            if (t > maxT) t = maxT;
+            t = maxT < 512 ? maxT : 512;
+            while (t < maxT && (long long)((K + (t / S) - 1) / (t / S)) > max_wg) t += 64;
         }
         if (t < 64) t = 64;
     }
@@ -412,6 +416,8 @@ extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, con
         a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
         a.final_eta = s->final_eta;
         a.timeout_ticks = 200000000ull;   // 2 s at 100 MHz
+        a.ablate = s->ablate;
+        a.stamps = s->stamp_pcg ? (unsigned long long *)s->sw.scalars + 8 : nullptr;
         a.ev_start = s->time_pcg ? s->ev_pcg0 : nullptr;
         a.ev_stop = s->time_pcg ? s->ev_pcg1 : nullptr;
         s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT;

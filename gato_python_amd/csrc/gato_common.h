@@ -31,6 +31,46 @@ __device__ __forceinline__ double fmaT(double a, double b, double c) { return __
         }                                                                                     \
     } while (0)
 
+// ---- wave64 sum on the DPP network (no LDS traffic): quad swaps, half-row / row mirrors, then the
+// gfx9 row broadcasts; the total lands in lane 63 and is returned wave-uniform.  Fixed order, so the
+// result is bitwise reproducible.  (A __shfl_xor butterfly compiles to six dependent ds_bpermute_b32,
+// each an LDS-crossbar round trip.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float lane63(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ double lane63(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum_dpp(T v)
+{
+    v += dpp_mov<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf>(v);   // row_half_mirror
+    v += dpp_mov<0x140, 0xf>(v);   // row_mirror      -> every lane holds its row's sum
+    v += dpp_mov<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
+    v += dpp_mov<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
+    return lane63(v);
+}
+
 // Device layout sizes in elements (gato_defines.h:32-37, gpu_library.cu:40-45).
 struct Dims {
     int S, C, K;
@@ -58,6 +98,8 @@ struct PcgLaunch {
     double *final_eta;           // device (optional)
     unsigned long long timeout_ticks;  // s_memrealtime ticks (100 MHz)
     hipEvent_t ev_start, ev_stop;      // optional: recorded right around the kernel launch
+    int ablate;                        // diagnostic: timing-only ablation mask (0 in production)
+    unsigned long long *stamps;        // optional: diagnostic cycle stamps (16 words), selects the STAMP build
 };
 
 // Granules (8 B: {epoch:32 | payload:32}) per workgroup and parity in the hand-off area.

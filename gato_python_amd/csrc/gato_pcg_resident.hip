@@ -39,12 +39,7 @@ __device__ __forceinline__ unsigned f2u(float x) { return __float_as_uint(x); }
 __device__ __forceinline__ float u2f(unsigned x) { return __uint_as_float(x); }
 
 template <typename T>
-__device__ __forceinline__ T wave_sum(T v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ T wave_sum(T v) { return wave_sum_dpp(v); }
 
 // ---- granule transport -------------------------------------------------------------------
 template <typename T> struct Granule;
@@ -54,6 +49,7 @@ template <> struct Granule<float> {
     {
         __hip_atomic_store(g, ((unsigned long long)ep << 32) | f2u(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __device__ static __forceinline__ float decode(const unsigned long long (&x)[1]) { return u2f((unsigned)x[0]); }
     // returns true when the tag matches; value in v
     __device__ static __forceinline__ bool load(gu64 *g, unsigned ep, float &v)
     {
@@ -69,6 +65,10 @@ template <> struct Granule<double> {
         unsigned long long b = (unsigned long long)__double_as_longlong(v);
         __hip_atomic_store(g, ((unsigned long long)ep << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(g + 1, ((unsigned long long)ep << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ static __forceinline__ double decode(const unsigned long long (&x)[2])
+    {
+        return __longlong_as_double((long long)((x[1] << 32) | (x[0] & 0xffffffffull)));
     }
     __device__ static __forceinline__ bool load(gu64 *g, unsigned ep, double &v)
     {
@@ -113,7 +113,19 @@ __device__ __forceinline__ T row_times_window(const T (&m)[3 * S], const T *xw)
     return acc;
 }
 
-template <typename T, int S, int MAXT>
+// STAMP: diagnostic build only - wave 0 of workgroup 0 accumulates s_memtime deltas per segment into
+// a.stamps (never used for timing claims; it perturbs the schedule).
+#define GATO_STAMP(i)                                                                       \
+    if (STAMP) {                                                                            \
+        if (wg == 0 && wave == 0) {                                                         \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+            seg[i] += t_ - t_prev;                                                          \
+            t_prev = t_;                                                                    \
+        }                                                                                   \
+    }
+
+template <typename T, int S, int MAXT, bool STAMP = false>
 __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 {
     typedef ResidentCfg<T, S, MAXT> Cfg;
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     constexpr int GPV = Gr::GPV;
 
     __shared__ __attribute__((aligned(16))) T xs[2][(Cfg::MAXK + 2) * SP];   // [0] = p window, [1] = r window
-    __shared__ T wpart[MAXT / 64];
+    __shared__ T wpart[2][MAXT / 64];   // per-wave partial dots, double-buffered by epoch parity
     __shared__ T gh[2][32];          // ghost blocks of the vector just gathered: [0] left, [1] right
     __shared__ T bc[2];              // broadcast scalars
     __shared__ int s_abort;
@@ -185,6 +197,12 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     }
     __syncthreads();
 
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = 0, t_begin = 0, rt_begin = 0;
+    if (STAMP) {
+        t_begin = t_prev = __builtin_amdgcn_s_memtime();
+        rt_begin = __builtin_amdgcn_s_memrealtime();
+    }
     unsigned epoch = 0;
     T eta = (T)0, eta_new = (T)0;
     int iters = a.max_iters;
@@ -194,48 +212,80 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // One reduction + halo exchange.  `val` = the vector just produced (upsilon or r~), `prod` the
     // lane's dot contribution.  On return: total in every thread; gh[][] = neighbours' boundary
     // blocks of `val` (zeros where there is no neighbour).
+    const int abl = a.ablate;     // diagnostic timing-only switches (results are garbage when set)
     auto allreduce_and_halo = [&](T val, T prod, T &total) {
         ++epoch;
+        if (abl & 4) { total = (T)1 + prod * (T)1e-30; return; }
         const T ws = wave_sum(prod);
-        if (lane == 0) wpart[wave] = ws;
+        T *wp = wpart[epoch & 1];
+        if (lane == 0) wp[wave] = ws;
         gu64 *mine = slots + ((size_t)(epoch & 1) * W + wg) * slotG;
         if (W > 1 && active) {
             if (j == 0) Gr::store(mine + 16 + r_ * GPV, epoch, val);
             if (j == nk - 1) Gr::store(mine + 16 + (S + r_) * GPV, epoch, val);
         }
         __syncthreads();                                                       // B1
+        if (W == 1) {
+            // one workgroup: every wave sums the per-wave partials itself (fixed order), no second barrier
+            // (one LDS read per lane + a DPP sum: a serial loop over the partials would pay one LDS
+            //  round trip per wave)
+            total = wave_sum(lane < nwaves ? wp[lane] : (T)0);
+            return;
+        }
         if (wave == 0) {
-            T tot = (T)0;
-            for (int w = 0; w < nwaves; ++w) tot += wpart[w];
-            if (W > 1) {
+            T tot = wave_sum(lane < nwaves ? wp[lane] : (T)0);
+            {
                 if (lane == 0) Gr::store(mine, epoch, tot);
-                // sweep: partials of all workgroups + neighbours' halo blocks
-                T pv[Cfg::PM];
-                T hv = (T)0;
+                // sweep: partials of all workgroups + neighbours' halo blocks.  Every lane issues ALL its loads
+                // back to back from clamped (always valid) addresses and waits once: predicated loads would each
+                // get their own s_waitcnt, i.e. one L2 round trip after the other.
                 gu64 *pbase = slots + (size_t)(epoch & 1) * W * slotG;
                 const bool want_l = has_left && lane < S;
                 const bool want_r = has_right && lane >= 32 && lane < 32 + S;
                 gu64 *hptr = want_l ? pbase + (size_t)(wg - 1) * slotG + 16 + (S + lane) * GPV
-                                    : pbase + (size_t)(wg + 1) * slotG + 16 + (lane - 32) * GPV;
+                           : want_r ? pbase + (size_t)(wg + 1) * slotG + 16 + (lane - 32) * GPV
+                                    : mine;
+                gu64 *pptr[Cfg::PM];
+#pragma unroll
+                for (int m = 0; m < Cfg::PM; ++m) pptr[m] = pbase + (size_t)min(lane + 64 * m, W - 1) * slotG;
+                const int pm_count = (W + 63) >> 6;           // wave-uniform
+                unsigned long long raw[Cfg::PM][GPV], hraw[GPV];
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 bool fail = false;
                 for (unsigned spin = 0;; ++spin) {
+#pragma unroll
+                    for (int m = 0; m < Cfg::PM; ++m) {
+                        if (m < pm_count) {
+#pragma unroll
+                            for (int g = 0; g < GPV; ++g)
+                                raw[m][g] = __hip_atomic_load(pptr[m] + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < GPV; ++g)
+                        hraw[g] = __hip_atomic_load(hptr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     bool ok = true;
 #pragma unroll
                     for (int m = 0; m < Cfg::PM; ++m) {
-                        const int q = lane + 64 * m;
-                        pv[m] = (T)0;
-                        if (q < W) ok &= Gr::load(pbase + (size_t)q * slotG, epoch, pv[m]);
+                        if (m < pm_count) {
+#pragma unroll
+                            for (int g = 0; g < GPV; ++g) ok &= (unsigned)(raw[m][g] >> 32) == epoch;
+                        }
                     }
-                    if (want_l || want_r) ok &= Gr::load(hptr, epoch, hv);
+#pragma unroll
+                    for (int g = 0; g < GPV; ++g) ok &= (unsigned)(hraw[g] >> 32) == epoch;   // own slot: always current
                     if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(1);
                     if ((spin & 255u) == 255u) {
                         const bool late = __builtin_amdgcn_s_memrealtime() - t0 > t_limit;
                         const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                         if (late || other) { fail = true; break; }
                     }
                 }
+                T pv[Cfg::PM];
+#pragma unroll
+                for (int m = 0; m < Cfg::PM; ++m)
+                    pv[m] = (m < pm_count && lane + 64 * m < W) ? Gr::decode(raw[m]) : (T)0;
+                const T hv = Gr::decode(hraw);
                 if (fail) {
                     if (lane == 0) {
                         __hip_atomic_store(g_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -270,9 +320,12 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 
         for (int it = 0; it < a.max_iters; ++it) {                              // gato_pcg.cuh:348
             // upsilon = S p ; v = p . upsilon                                     (:349-357)
-            ups = row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
+            GATO_STAMP(5)
+            ups = (abl & 1) ? p * sm[0] : row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
+            GATO_STAMP(0)
             T v;
             allreduce_and_halo(ups, p * ups, v);
+            GATO_STAMP(1)
             if (aborted) break;
             const T alpha = eta / v;                                            // :364
             lam += alpha * p;                                                   // :373-377
@@ -282,10 +335,13 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 if (tid < S) xs[1][tid] -= alpha * gh[0][tid];
                 else if (tid < 2 * S) xs[1][(nk + 1) * SP + (tid - S)] -= alpha * gh[1][tid - S];
             }
-            __syncthreads();                                                    // B3
+            if (!(abl & 8)) __syncthreads();                                    // B3
+            GATO_STAMP(2)
             // r~ = Pinv r ; eta' = r . r~                                        (:380-394)
-            rt = row_times_window<T, S, SP>(pm, &xs[1][j * SP]);
+            rt = (abl & 2) ? r * pm[0] : row_times_window<T, S, SP>(pm, &xs[1][j * SP]);
+            GATO_STAMP(3)
             allreduce_and_halo(rt, r * rt, eta_new);
+            GATO_STAMP(4)
             if (aborted) break;
             if (fabs(eta_new) < tol) { iters = it; break; }                     // :404-411
             const T beta = eta_new / eta;                                       // :415
@@ -296,13 +352,18 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = gh[1][tid - S] + beta * xs[0][(nk + 1) * SP + (tid - S)];
             }
             eta = eta_new;                                                      // :420
-            __syncthreads();                                                    // B6
+            if (!(abl & 8)) __syncthreads();                                    // B6
         }
     }
     if (active) dL[(size_t)k * S + r_] = lam;                                   // :433-435
     if (wg == 0 && tid == 0) {
         *a.iters = iters;
         if (a.final_eta) *a.final_eta = (double)eta_new;
+        if (STAMP && a.stamps) {
+            for (int i = 0; i < 8; ++i) a.stamps[i] = seg[i];
+            a.stamps[8] = __builtin_amdgcn_s_memtime() - t_begin;
+            a.stamps[9] = __builtin_amdgcn_s_memrealtime() - rt_begin;
+        }
     }
 }
 
@@ -342,7 +403,8 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
     if (a.groups > 1) GATO_HIP_CHECK(hipMemsetAsync(a.slots, 0, slot_bytes, st));
     GATO_HIP_CHECK(hipMemsetAsync(a.status, 0, sizeof(int), st));
     if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-    hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT>), dim3(a.groups), dim3(a.threads), 0, st, a);
+    if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT, true>), dim3(a.groups), dim3(a.threads), 0, st, a);
+    else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT, false>), dim3(a.groups), dim3(a.threads), 0, st, a);
     GATO_HIP_CHECK(hipGetLastError());
     if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
     return GATO_OK;
