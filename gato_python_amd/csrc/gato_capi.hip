@@ -107,7 +107,7 @@ struct gato_solver {
     char *in_arena;
     size_t in_bytes;
     int last_groups, last_threads, last_mode;
-    int time_pcg, stamp_pcg, ablate;
+    int time_pcg, stamp_pcg, ablate, no_single_lds;
     hipEvent_t ev_pcg0, ev_pcg1;
     // knot-sharded PCG state (gato_shard_pcg_*)
     struct {
@@ -297,6 +297,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "pcg_groups")) s->pcg_groups = value;
     else if (!strcmp(name, "stamp_pcg")) s->stamp_pcg = value;
     else if (!strcmp(name, "ablate")) s->ablate = value;
+    else if (!strcmp(name, "no_single_lds")) s->no_single_lds = value;
     else if (!strcmp(name, "time_pcg")) {
         s->time_pcg = value;
         if (value && !s->ev_pcg0) {
@@ -378,6 +379,10 @@ static int plan_resident(gato_solver *s, int *groups, int *threads, int *kpw)
         // of the operand window, and W stays small enough that one wave sweeps all partial granules),
         // growing only if that would need more workgroups than CUs.
         if (K * S <= maxT) t = (K * S + 63) / 64 * 64;
+        else if (K * S <= s->plan.single_max_threads && g <= 1 && !s->no_single_lds) {
+            *groups = 1; *threads = (K * S + 63) / 64 * 64; *kpw = K;      // one CU, Pinv rows partly in LDS
+            return 1;
+        }
         else {
             t = maxT < 512 ? maxT : 512;
             while (t < maxT && (long long)((K + (t / S) - 1) / (t / S)) > max_wg) t += 64;

@@ -114,6 +114,7 @@ __host__ __device__ inline int pcg_slot_granules(int S, int esz)
 struct PcgPlan {
     int max_threads;     // launch bound of the instantiation
     int max_knots_per_wg;
+    int single_max_threads;   // > max_threads: a one-workgroup variant (Pinv rows partly in LDS) exists up to this size
 };
 
 // Per-(dtype, S, C) kernel launchers, defined in the .hip files and instantiated for GATO_SHAPES.

@@ -125,7 +125,37 @@ __device__ __forceinline__ T row_times_window(const T (&m)[3 * S], const T *xw)
         }                                                                                   \
     }
 
-template <typename T, int S, int MAXT, bool STAMP = false>
+// Same product with the last NL entries of the row read from LDS (16 B per lane, lane-contiguous: conflict
+// free) instead of registers.  Needs S % VW == 0 and (3S-NL) % VW == 0 so that vectors never straddle blocks.
+template <typename T, int S, int SP, int NL, int MAXT>
+__device__ __forceinline__ T row_times_window_lds(const T (&m)[3 * S - NL], const typename VecOf<T>::type (*tail)[MAXT],
+                                                  int tid, const T *xw)
+{
+    typedef typename VecOf<T>::type V;
+    constexpr int VW = VecOf<T>::W;
+    constexpr int NREG = 3 * S - NL;
+    static_assert(S % VW == 0 && NREG % VW == 0 && NL % VW == 0, "vector alignment");
+    T acc = (T)0;
+#pragma unroll
+    for (int c = 0; c < NREG; c += VW) {
+        V v = *reinterpret_cast<const V *>(xw + (c / S) * SP + (c % S));
+#pragma unroll
+        for (int e = 0; e < VW; ++e) acc = gato::fmaT(m[c + e], v[e], acc);
+    }
+#pragma unroll
+    for (int c = NREG; c < 3 * S; c += VW) {
+        V v = *reinterpret_cast<const V *>(xw + (c / S) * SP + (c % S));
+        V mv = tail[(c - NREG) / VW][tid];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) acc = gato::fmaT(mv[e], v[e], acc);
+    }
+    return acc;
+}
+
+// NL > 0: single-workgroup variant whose Pinv rows do not fit the register budget: the last NL entries of
+// every Pinv row live in LDS (IIWA 14/7/50 in fp64: 700 rows x 84 doubles = 470 KB > the 168 VGPRs/lane that
+// 11 waves on one CU leave; 24 doubles per row = 135 KB go to LDS, the rest stays in registers).
+template <typename T, int S, int MAXT, int NL = 0, bool STAMP = false>
 __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 {
     typedef ResidentCfg<T, S, MAXT> Cfg;
@@ -134,7 +164,10 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     constexpr int GPV = Gr::GPV;
 
     __shared__ __attribute__((aligned(16))) T xs[2][(Cfg::MAXK + 2) * SP];   // [0] = p window, [1] = r window
-    __shared__ T wpart[2][MAXT / 64];   // per-wave partial dots, double-buffered by epoch parity
+    __shared__ T wpart[2][(MAXT + 63) / 64];   // per-wave partial dots, double-buffered by epoch parity
+    typedef typename VecOf<T>::type V;
+    constexpr int NREG = 3 * S - NL;
+    __shared__ __attribute__((aligned(16))) V ptail[NL > 0 ? NL / VecOf<T>::W : 1][NL > 0 ? MAXT : 1];
     __shared__ T gh[2][32];          // ghost blocks of the vector just gathered: [0] left, [1] right
     __shared__ T bc[2];              // broadcast scalars
     __shared__ int s_abort;
@@ -143,7 +176,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int nwaves = blockDim.x >> 6;
-    const int W = gridDim.x;
+    const int W = NL > 0 ? 1 : (int)gridDim.x;      // the LDS-tail variant is single-workgroup by construction
     const int wg = blockIdx.x;
     const int K = a.K;
     const int k0 = wg * a.knots_per_wg;
@@ -164,14 +197,16 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // bd layout: block-row k = [left|main|right], each S*S column-major -> element (r, c) of the
     // S x 3S strip sits at c*S + r (gato_utils.cuh:53-54,97-98).  First/last block rows have no
     // left/right block (gato_utils.cuh:157-174): those entries are forced to zero here.
-    T sm[3 * S], pm[3 * S];
+    T sm[3 * S], pm[NREG];
     {
         const size_t base = (size_t)(active ? k : 0) * 3 * S * S + r_;
 #pragma unroll
         for (int c = 0; c < 3 * S; ++c) {
             const bool ok = active && !(k == 0 && c < S) && !(k == K - 1 && c >= 2 * S);
             sm[c] = ok ? dS[base + (size_t)c * S] : (T)0;
-            pm[c] = ok ? dP[base + (size_t)c * S] : (T)0;
+            const T pv_ = ok ? dP[base + (size_t)c * S] : (T)0;
+            if (c < NREG) pm[c < NREG ? c : 0] = pv_;
+            else ptail[(c - NREG) / VecOf<T>::W][tid][(c - NREG) % VecOf<T>::W] = pv_;   // own lane only: no barrier
         }
     }
 
@@ -307,7 +342,11 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     };
 
     // ---- r~ = Pinv r ; p = r~ ; eta = r . r~   (gato_pcg.cuh:316-335) ------------------------
-    rt = row_times_window<T, S, SP>(pm, &xs[1][j * SP]);
+    auto pinv_times = [&](const T *xw) -> T {
+        if constexpr (NL > 0) return row_times_window_lds<T, S, SP, NL, MAXT>(pm, ptail, tid, xw);
+        else return row_times_window<T, S, SP>(pm, xw);
+    };
+    rt = pinv_times(&xs[1][j * SP]);
     allreduce_and_halo(rt, r * rt, eta);
     if (!aborted) {
         p = rt;
@@ -338,7 +377,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             if (!(abl & 8)) __syncthreads();                                    // B3
             GATO_STAMP(2)
             // r~ = Pinv r ; eta' = r . r~                                        (:380-394)
-            rt = (abl & 2) ? r * pm[0] : row_times_window<T, S, SP>(pm, &xs[1][j * SP]);
+            rt = (abl & 2) ? r * pm[0] : pinv_times(&xs[1][j * SP]);
             GATO_STAMP(3)
             allreduce_and_halo(rt, r * rt, eta_new);
             GATO_STAMP(4)
@@ -380,18 +419,26 @@ template <> struct MaxThreads<double, 32> { static constexpr int v = 256; };
 
 }  // namespace
 
+// Single-workgroup variants with part of the Pinv rows in LDS: (threads, NL).
+template <typename T, int S> struct SingleCu { static constexpr int threads = 0, nl = 0; };
+template <> struct SingleCu<double, 14> { static constexpr int threads = 704, nl = 24; };   // IIWA 14/7/50 fp64
+
 template <typename T, int S>
 int pcg_resident_plan(PcgPlan *plan)
 {
     plan->max_threads = MaxThreads<T, S>::v;
     plan->max_knots_per_wg = MaxThreads<T, S>::v / S;
+    plan->single_max_threads = SingleCu<T, S>::threads;
     return GATO_OK;
 }
 
 template <typename T, int S>
 int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
 {
-    constexpr int MAXT = MaxThreads<T, S>::v;
+    constexpr int MAXT0 = MaxThreads<T, S>::v;
+    constexpr int SINGLE_T = SingleCu<T, S>::threads;
+    const bool single_lds = SINGLE_T > MAXT0 && a.groups == 1 && a.threads > MAXT0 && a.threads <= SINGLE_T;
+    const int MAXT = single_lds ? SINGLE_T : MAXT0;
     if (a.threads > MAXT || a.threads % 64 != 0 || a.threads < 2 * S || a.knots_per_wg * S > a.threads ||
         a.groups < 1 || a.groups > 256 || (long long)a.groups * a.knots_per_wg < a.K ||
         (long long)(a.groups - 1) * a.knots_per_wg >= a.K) {
@@ -403,8 +450,18 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
     if (a.groups > 1) GATO_HIP_CHECK(hipMemsetAsync(a.slots, 0, slot_bytes, st));
     GATO_HIP_CHECK(hipMemsetAsync(a.status, 0, sizeof(int), st));
     if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-    if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT, true>), dim3(a.groups), dim3(a.threads), 0, st, a);
-    else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT, false>), dim3(a.groups), dim3(a.threads), 0, st, a);
+    if constexpr (SINGLE_T > 0) {
+        if (single_lds) {
+            constexpr int NL = SingleCu<T, S>::nl;
+            if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, true>), dim3(1), dim3(a.threads), 0, st, a);
+            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, false>), dim3(1), dim3(a.threads), 0, st, a);
+            GATO_HIP_CHECK(hipGetLastError());
+            if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
+            return GATO_OK;
+        }
+    }
+    if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, true>), dim3(a.groups), dim3(a.threads), 0, st, a);
+    else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false>), dim3(a.groups), dim3(a.threads), 0, st, a);
     GATO_HIP_CHECK(hipGetLastError());
     if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
     return GATO_OK;

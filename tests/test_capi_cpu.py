@@ -90,3 +90,16 @@ def test_product_code_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libgato_oracle" not in txt, f
     assert "oracle" not in open(os.path.join(ROOT, "gpu_library.py")).read().replace("KKT oracle", "")
+
+
+def test_pybind11_module_builds_and_imports():
+    """The pybind11 `gpu_library` (bindings/pybind11) exposes exactly the reference's surface."""
+    import subprocess
+    import sys
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "bindings", "pybind11"), "-s"])
+    code = ("import gpu_library, inspect; assert gpu_library.__file__.endswith('.so'), gpu_library.__file__; "
+            "names=[n for n in dir(gpu_library) if not n.startswith('_')]; assert names==['linsys_solve'], names; "
+            "print('ok')")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "bindings", "pybind11", "build"))
+    r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

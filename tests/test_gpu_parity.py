@@ -135,7 +135,9 @@ def test_golden_fp64_whole_solve(golden_dir, name, S, C, K, seed, dq, tol, mi):
 
 @pytest.mark.parametrize("S,C,K,dt,opts", [
     (14, 7, 50, np.float32, {}),                                  # one workgroup
-    (14, 7, 50, np.float64, {}),                                  # two workgroups (register budget)
+    (14, 7, 50, np.float64, {}),                                  # one workgroup, Pinv row tails in LDS
+    (14, 7, 50, np.float64, dict(no_single_lds=1)),               # two workgroups (register budget)
+    (14, 7, 37, np.float64, {}),                                  # LDS-tail variant with idle lanes
     (14, 7, 50, np.float32, dict(pcg_groups=7)),                  # forced ragged split
     (14, 7, 50, np.float64, dict(pcg_threads=64)),                # 4 knots per workgroup, 13 groups
     (14, 7, 512, np.float32, {}),
@@ -261,3 +263,28 @@ def test_dropin_accepts_numpy_and_env_shape(monkeypatch):
                                      np.zeros(700), 1, 1e-6, 100, False, s.rho)
         finally:
             gpu_library.clear_problem_size()
+
+
+def test_pybind11_module_runs_the_reference_test(golden_dir):
+    """bindings/pybind11: the reference's own script flow (test_pendulum_5.py:25-37) against the pybind11
+    module built over the C ABI, in a fresh interpreter that cannot see the ctypes drop-in."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import json, numpy as np, gpu_library
+assert gpu_library.__file__.endswith('.so')
+gold = json.load(open({os.path.join(golden_dir, 'pendulum.json')!r}))
+i, e = gold['inputs'], gold['expected']
+l, dz = gpu_library.linsys_solve(i['G_row'], i['G_col'], i['G_val'], i['C_row'], i['C_col'], i['C_val'], i['g_val'],
+                                 i['c_val'], i['input_lambda'], i['testiters'], i['exit_tol'], i['max_iters'],
+                                 i['warm_start'], i['rho'])
+x = np.concatenate([e['dense_kkt_norho_dz'], e['dense_kkt_norho_lam']])
+assert np.allclose(np.concatenate([dz, l]), x, rtol=1, atol=0.01)
+assert np.abs(np.asarray(l) - e['lam']).max() / np.abs(e['lam']).max() < 5e-5
+print('Test passed')
+"""
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "bindings", "pybind11", "build"), GATO_VERBOSE="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Test passed" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "first run PCG terminated in 5 iterations" in r.stdout and "avg time:" in r.stdout

@@ -4,13 +4,17 @@
   profiles/pmc_traffic.json        - HBM bytes per PCG launch per bench workload from the PMC passes
     python tools/summarize_profile.py r01
 """
-import csv, glob, json, os, shutil, sys
+import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
+
+
+def short(name):
+    return re.sub(r"^void gato::\(anonymous namespace\)::", "", name).split("(")[0]
 
 
 def one(pattern):
@@ -26,7 +30,7 @@ launch = defaultdict(list)
 if trace:
     for r in csv.DictReader(open(trace)):
         if "pcg_" in r["Kernel_Name"] or "stream_step" in r["Kernel_Name"]:
-            key = (r["Kernel_Name"].split("(")[0].replace("void gato::(anonymous namespace)::", ""),
+            key = (short(r["Kernel_Name"]),
                    int(r["Grid_Size_X"] if "Grid_Size_X" in r else r["Grid_Size"]),
                    int(r["Workgroup_Size_X"] if "Workgroup_Size_X" in r else r["Workgroup_Size"]))
             launch[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -42,8 +46,7 @@ def counter(kind):
     if p:
         for r in csv.DictReader(open(p)):
             if "pcg_" in r["Kernel_Name"] or "stream_step" in r["Kernel_Name"]:
-                key = (r["Kernel_Name"].split("(")[0].replace("void gato::(anonymous namespace)::", ""),
-                       int(r["Grid_Size"]), int(r["Workgroup_Size"]))
+                key = (short(r["Kernel_Name"]), int(r["Grid_Size"]), int(r["Workgroup_Size"]))
                 acc[key].append(float(r["Counter_Value"]))
     return acc
 
@@ -70,8 +73,10 @@ for name, (prefix, K) in WL.items():
             f_kb = sum(fetch[key]) / len(fetch[key])
             w_kb = sum(write[key]) / len(write[key]) if key in write else 0.0
             traffic[name] = dict(kernel=key[0], grid_threads=key[1], fetch_size_kb=f_kb, write_size_kb=w_kb,
-                                 hbm_bytes_per_launch=(f_kb + w_kb) * 1024,
-                                 note="FETCH_SIZE taken as reported (narrow 4/8-byte loads: the x2 correction of "
-                                      "MI355X_MICROARCH.md applies to 16-B-per-lane streams only); launches=%d" % len(fetch[key]))
+                                 hbm_bytes_per_launch=(2 * f_kb + w_kb) * 1024,
+                                 note="HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB: gfx950 FETCH_SIZE reports half the "
+                                      "fetched bytes (MI355X_MICROARCH.md, HBM section); calibrated here on the K=50 "
+                                      "launches, where 2 x FETCH_SIZE equals the S + Pinv bytes read once. launches=%d"
+                                      % len(fetch[key]))
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(out)))
