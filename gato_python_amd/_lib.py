@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libgato_hip.so")
+SO_PATH = os.environ.get("GATO_HIP_LIB") or os.path.join(_HERE, "libgato_hip.so")   # override: A/B builds only
 _LIB = None
 
 GATO_F32, GATO_F64 = 0, 1

@@ -27,23 +27,36 @@ template <typename T> struct Vec16;
 template <> struct Vec16<float> { typedef float __attribute__((ext_vector_type(4))) type; static constexpr int W = 4; };
 template <> struct Vec16<double> { typedef double __attribute__((ext_vector_type(2))) type; static constexpr int W = 2; };
 
+#ifndef GATO_STREAM_TILE_BYTES
+#define GATO_STREAM_TILE_BYTES (38 * 1024)   /* measured best on MI355X (tools/stream_bench.py): 2 workgroups per CU */
+#endif
+#ifndef GATO_STREAM_AUX
+#define GATO_STREAM_AUX 2   /* cache policy of the LDS-DMA tile loads: 0 default, 2 = nt (each block row is read once per launch: +7 %) */
+#endif
+#ifndef GATO_STREAM_MAX_ROWS
+#define GATO_STREAM_MAX_ROWS 256
+#endif
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// Tile = KT consecutive block rows (one contiguous byte range of the bd layout), about 38 KB, double buffered in
+// LDS: 2 workgroups per CU keep ~76 KB of HBM loads in flight per CU.
 template <typename T, int S>
 struct StreamCfg {
+    static constexpr int VW = Vec16<T>::W;
     static constexpr int ROW = 3 * S * S;                                   // elements per block row
-    static constexpr int KT_LDS = (48 * 1024) / (ROW * (int)sizeof(T));      // tile <= 48 KiB of LDS
-    static constexpr int KT_THR = 256 / S;
-    static constexpr int KT = KT_LDS < KT_THR ? (KT_LDS < 1 ? 1 : KT_LDS) : KT_THR;
+    static constexpr int KT = cmax(1, cmin(GATO_STREAM_TILE_BYTES / (ROW * (int)sizeof(T)), GATO_STREAM_MAX_ROWS / S));
     static constexpr int THREADS = (KT * S + 63) / 64 * 64;
     static constexpr int NWAVES = THREADS / 64;
+    static constexpr int SPX = (S + VW - 1) / VW * VW;                      // padded knot stride of the operand window
+    static constexpr int XW = (KT + 2) * SPX;
+    static constexpr int NVP = ((KT + 2) * S + THREADS - 1) / THREADS;      // window elements prefetched per thread
+    static constexpr int TILE_BYTES = KT * ROW * (int)sizeof(T);
+    static constexpr int LDS_BYTES = 2 * TILE_BYTES + 2 * XW * (int)sizeof(T) + 64;
 };
 
 template <typename T>
-__device__ __forceinline__ T wave_sum(T v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ T wave_sum(T v) { return wave_sum_dpp(v); }
 
 // Sum of n slot values in a fixed order, identical in every workgroup.  red: NWAVES elements of LDS.
 template <typename T, int THREADS>
@@ -72,13 +85,13 @@ __global__ __launch_bounds__((StreamCfg<T, S>::THREADS)) void stream_step_kernel
 {
     typedef StreamCfg<T, S> Cfg;
     typedef typename Vec16<T>::type V;
-    constexpr int VW = Vec16<T>::W;
-    constexpr int ROW = Cfg::ROW, KT = Cfg::KT, THREADS = Cfg::THREADS;
-    __shared__ __attribute__((aligned(16))) T tile[KT * ROW];
-    __shared__ T xw[(KT + 2) * S];
+    constexpr int VW = Cfg::VW, ROW = Cfg::ROW, KT = Cfg::KT, THREADS = Cfg::THREADS, SPX = Cfg::SPX, NVP = Cfg::NVP;
+    __shared__ __attribute__((aligned(16))) T tile[2][KT * ROW];   // LDS-DMA destination, double buffered
+    __shared__ __attribute__((aligned(16))) T xw[2][Cfg::XW];
     __shared__ T red[Cfg::NWAVES];
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int K = a.K;
     if (PHASE != 0 && *a.done) return;
 
@@ -103,83 +116,136 @@ __global__ __launch_bounds__((StreamCfg<T, S>::THREADS)) void stream_step_kernel
         *a.iters = a.max_iters;
     }
 
-    const T *__restrict__ M = (const T *)a.M;
+    const char *__restrict__ Mb = (const char *)a.M;
     const T *__restrict__ a_old = (const T *)a.a_old;
     const T *__restrict__ b = (const T *)a.b;
     T *__restrict__ a_new = (T *)a.a_new;
     T *__restrict__ y = (T *)a.y;
+    T *__restrict__ lam = (T *)a.lam;
+    const T *__restrict__ p_cur = (const T *)a.p_cur;
     const bool use_old = PHASE == 2 || (PHASE == 1 && a.it > 0);
+    const long long nrows = (long long)K * S;
 
     const int j = tid / S, r = tid - j * S;
-    T part = (T)0;
     const int ntiles = (K + KT - 1) / KT;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+
+    // asynchronous tile load: 1 KiB per wave-instruction straight into LDS (global_load_lds_dwordx4)
+    auto issue_tile = [&](int t, int buf) {
         const int kt = t * KT;
         const int nk = min(KT, K - kt);
-        __syncthreads();   // previous tile fully consumed
-        // stage the matrix tile: contiguous range of the bd layout, 16 B per lane per load
-        {
-            const V *__restrict__ src = reinterpret_cast<const V *>(M + (size_t)kt * ROW);
-            V *dst = reinterpret_cast<V *>(tile);
-            const int nvec = nk * (ROW / VW);
-            for (int i = tid; i < nvec; i += THREADS) {
-                V v = src[i];
-                const int e = i * VW;
-                const int kk = kt + e / ROW, within = e % ROW;
-                // first block row has no left block, last no right block (gato_utils.cuh:157-174)
-                if ((a.first_global && kk == 0 && within < S * S) ||
-                    (a.last_global && kk == K - 1 && within >= 2 * S * S)) v = (V)(T)0;
-                dst[i] = v;
-            }
+        const int bytes = nk * ROW * (int)sizeof(T);
+        const char *src = Mb + (size_t)kt * ROW * sizeof(T);
+        char *dst = (char *)&tile[buf][0];
+        for (int q = wave; q * 1024 < bytes; q += Cfg::NWAVES) {
+            const int off = q * 1024 + lane * 16;
+            if (off < bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                 (__attribute__((address_space(3))) void *)(dst + q * 1024), 16, 0, GATO_STREAM_AUX);
         }
-        // rebuild the operand window for knots kt-1 .. kt+nk  (fused AXPY of the previous phase)
-        for (int i = tid; i < (nk + 2) * S; i += THREADS) {
-            const long long gi = (long long)(kt - 1) * S + i;
-            T x = (T)0;
-            if (gi >= 0 && gi < (long long)K * S) {
-                if (PHASE == 0) x = a_old[gi];                                   // r = gamma
-                else if (PHASE == 1) x = b[gi] + coef * (use_old ? a_old[gi] : (T)0);   // p = r~ + beta p
-                else x = a_old[gi] - coef * b[gi];                               // r = r - alpha upsilon
-                if (i >= S && i < (nk + 1) * S) a_new[gi] = x;                   // own rows only
-            } else {
-                // block of a neighbouring shard: advance the ghost with the neighbour's boundary block
-                const bool left = gi < 0;
-                const bool have = left ? !a.first_global : !a.last_global;
-                if (have) {
-                    const int e = left ? (int)(gi + S) : (int)(gi - (long long)K * S);
-                    const T *ga = (const T *)(left ? a.gh_a_left : a.gh_a_right);
-                    const T *gb = (const T *)(left ? a.gh_b_left : a.gh_b_right);
-                    if (PHASE == 0) x = ga[e];
-                    else if (PHASE == 1) x = gb[e] + coef * (use_old ? ga[e] : (T)0);
-                    else x = ga[e] - coef * gb[e];
-                    T *gn = (T *)(left ? a.gh_new_left : a.gh_new_right);
-                    gn[e] = x;                                                   // one writer: first / last tile
+    };
+    // operand-window elements of tile t this thread is responsible for: values of a_old / b (own rows or ghosts)
+    T pa[NVP], pb[NVP], pp = (T)0, pl = (T)0;
+    auto prefetch_vec = [&](int t) {
+        const int kt = t * KT;
+        const int nk = min(KT, K - kt);
+#pragma unroll
+        for (int m = 0; m < NVP; ++m) {
+            const int i = tid + m * THREADS;
+            pa[m] = (T)0; pb[m] = (T)0;
+            if (i < (nk + 2) * S) {
+                const long long gi = (long long)(kt - 1) * S + i;
+                if (gi >= 0 && gi < nrows) {
+                    if (PHASE == 0 || use_old) pa[m] = a_old[gi];
+                    if (PHASE != 0) pb[m] = b[gi];
+                } else {
+                    const bool left = gi < 0;
+                    if (left ? !a.first_global : !a.last_global) {
+                        const int e = left ? (int)(gi + S) : (int)(gi - nrows);
+                        const T *ga = (const T *)(left ? a.gh_a_left : a.gh_a_right);
+                        const T *gb = (const T *)(left ? a.gh_b_left : a.gh_b_right);
+                        if (PHASE == 0 || use_old) pa[m] = ga[e];
+                        if (PHASE != 0) pb[m] = gb[e];
+                    }
                 }
             }
-            xw[i] = x;
         }
+        if (PHASE == 2 && j < nk) {
+            const size_t gi = (size_t)(kt + j) * S + r;
+            pp = p_cur[gi];
+            pl = lam[gi];
+        }
+    };
+
+    T part = (T)0;
+    int t = blockIdx.x;
+    if (t < ntiles) { issue_tile(t, 0); prefetch_vec(t); }
+    for (int n = 0; t < ntiles; t += gridDim.x, ++n) {
+        const int buf = n & 1;
+        const int kt = t * KT;
+        const int nk = min(KT, K - kt);
+        // the tile and the vector values were requested one iteration ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // rebuild the operand window for knots kt-1 .. kt+nk  (fused AXPY of the previous phase)
+        T *xb = xw[buf];
+#pragma unroll
+        for (int m = 0; m < NVP; ++m) {
+            const int i = tid + m * THREADS;
+            if (i < (nk + 2) * S) {
+                T x;
+                if (PHASE == 0) x = pa[m];                                       // r = gamma
+                else if (PHASE == 1) x = pb[m] + coef * pa[m];                   // p = r~ + beta p   (pa = 0 at it 0)
+                else x = pa[m] - coef * pb[m];                                   // r = r - alpha upsilon
+                const long long gi = (long long)(kt - 1) * S + i;
+                if (gi >= 0 && gi < nrows) {
+                    if (i >= S && i < (nk + 1) * S) a_new[gi] = x;               // own rows only
+                } else {
+                    const bool left = gi < 0;
+                    if (left ? !a.first_global : !a.last_global) {               // ghost of a neighbouring shard
+                        T *gn = (T *)(left ? a.gh_new_left : a.gh_new_right);
+                        gn[left ? (int)(gi + S) : (int)(gi - nrows)] = x;        // one writer: first / last tile
+                    } else x = (T)0;
+                }
+                xb[(i / S) * SPX + (i % S)] = x;
+            }
+        }
+        const T my_p = pp, my_l = pl;
         __syncthreads();
+        // first block row has no left block, last no right block (gato_utils.cuh:157-174): those blocks may hold
+        // anything in the caller's buffer, so they are cleared in LDS after the DMA landed
+        const bool clr_first = a.first_global && kt == 0, clr_last = a.last_global && kt + nk == K;
+        if (clr_first || clr_last) {
+            if (clr_first) for (int i = tid; i < S * S; i += THREADS) tile[buf][i] = (T)0;
+            if (clr_last) for (int i = tid; i < S * S; i += THREADS) tile[buf][(nk - 1) * ROW + 2 * S * S + i] = (T)0;
+            __syncthreads();
+        }
+        // request the next tile while this one is consumed
+        const int tn = t + gridDim.x;
+        if (tn < ntiles) { issue_tile(tn, buf ^ 1); prefetch_vec(tn); }
         if (j < nk) {
-            const T *mrow = tile + j * ROW + r;
-            const T *xv = xw + j * S;
+            const T *mrow = &tile[buf][j * ROW + r];
+            const T *xv = xb + j * SPX;
             T acc = (T)0;
 #pragma unroll
-            for (int c = 0; c < 3 * S; ++c) acc = gato::fmaT(mrow[c * S], xv[c], acc);
+            for (int bk = 0; bk < 3; ++bk) {
+#pragma unroll
+                for (int i = 0; i < SPX / VW; ++i) {
+                    const V v = *reinterpret_cast<const V *>(xv + bk * SPX + i * VW);
+#pragma unroll
+                    for (int e = 0; e < VW; ++e)
+                        if (i * VW + e < S) acc = gato::fmaT(mrow[(bk * S + i * VW + e) * S], v[e], acc);
+                }
+            }
             const size_t gi = (size_t)(kt + j) * S + r;
             y[gi] = acc;
-            part += xv[S + r] * acc;
-            if (PHASE == 2) {
-                T *lam = (T *)a.lam;
-                lam[gi] += coef * ((const T *)a.p_cur)[gi];                      // gato_pcg.cuh:150-153
-            } else if (PHASE == 0) {
-                ((T *)a.lam)[gi] = (T)0;
-            }
+            part += xv[SPX + r] * acc;
+            if (PHASE == 2) lam[gi] = my_l + coef * my_p;                        // gato_pcg.cuh:150-153
+            else if (PHASE == 0) lam[gi] = (T)0;
         }
     }
     // one slot per workgroup
     part = wave_sum(part);
     __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = part;
+    if (lane == 0) red[wave] = part;
     __syncthreads();
     if (tid == 0) {
         T tot = (T)0;
@@ -223,8 +289,14 @@ int stream_grid(int K, int max_groups)
 {
     typedef StreamCfg<T, S> Cfg;
     const int ntiles = (K + Cfg::KT - 1) / Cfg::KT;
-    int grid = ntiles < max_groups ? ntiles : max_groups;
-    return grid > 2048 ? 2048 : grid;
+    // persistent grid: as many workgroups as fit the chip at once (LDS-limited), each walks tiles grid-stride
+    int per_cu = (160 * 1024) / Cfg::LDS_BYTES;
+    per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+    if (per_cu * Cfg::THREADS > 2048) per_cu = 2048 / Cfg::THREADS;
+    int grid = 256 * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    if (grid > max_groups) grid = max_groups;
+    return grid;
 }
 
 template <typename T, int S>
