@@ -18,7 +18,10 @@ namespace {
 constexpr int WAVE = 64;
 
 // ---- A1 ------------------------------------------------------------------------------------
-// One thread per CSR row (rows of G first, then rows of C), as the reference; outputs pre-zeroed.
+// The reference walks each CSR row with one thread (gato_schur.cuh:674-743): a chain of dependent loads per
+// entry.  Here a thread owns ONE (row, slot) pair - slot = position inside the row, rows longer than SLOTS are
+// walked with stride SLOTS - so a solve's scatter is two dependent loads deep (indptr -> col/val -> store).
+// Same arithmetic and same destination per entry as the reference; outputs pre-zeroed.
 template <typename T, int S, int C>
 __global__ void convert_kernel(const int *__restrict__ G_row, const int *__restrict__ G_col,
                                const T *__restrict__ G_val, const int *__restrict__ C_row,
@@ -26,14 +29,18 @@ __global__ void convert_kernel(const int *__restrict__ G_row, const int *__restr
                                T *__restrict__ Gd, T *__restrict__ Cd)
 {
     constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C;
+    constexpr int SLOTS = 32;                                   // >= S + C + 1 for the compiled shapes' C rows
     const int N = n * K - C;
     const int SK = S * K;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < N + SK; t += gridDim.x * blockDim.x) {
-        if (t < N) {                                            // csr_to_custom_G, gato_schur.cuh:674-704
-            const int row = t;
+    const long long total = (long long)(N + SK) * SLOTS;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int rr = (int)(t / SLOTS), slot = (int)(t % SLOTS);
+        if (rr < N) {                                           // csr_to_custom_G, gato_schur.cuh:674-704
+            const int row = rr;
             const int in_set_row = row % n;
             const size_t set_offset = (size_t)(row / n) * (SS + CC);
-            for (int it = G_row[row]; it < G_row[row + 1]; ++it) {
+            const int end = G_row[row + 1];
+            for (int it = G_row[row] + slot; it < end; it += SLOTS) {
                 const int col = G_col[it];
                 const int in_set_col = col % n;
                 const T v = G_val[it] + (col == row ? rho : (T)0);
@@ -41,10 +48,11 @@ __global__ void convert_kernel(const int *__restrict__ G_row, const int *__restr
                 else Gd[set_offset + SS + (in_set_col - S) * C + (in_set_row - S)] = v;
             }
         } else {                                                // csr_to_custom_C, :707-743
-            const int row = t - N;
+            const int row = rr - N;
             if (row < S) continue;
             const int block_row = row / S - 1;
-            for (int it = C_row[row]; it < C_row[row + 1]; ++it) {
+            const int end = C_row[row + 1];
+            for (int it = C_row[row] + slot; it < end; it += SLOTS) {
                 const int col = C_col[it];
                 if (col / n > block_row) continue;
                 Cd[(size_t)block_row * (SS + SC) + (col % n) * S + row % S] = C_val[it];
@@ -71,9 +79,11 @@ __device__ void gj_inverse(T *A, T *Ainv, T *tmp, int lane)
     wave_sync();
     T *colv = tmp, *rowA = tmp + n, *rowI = tmp + 2 * n;
     for (int p = 0; p < n; ++p) {
-        const T pv = A[p + p * n];
+        // one reciprocal per pivot (the single-matrix overload's pvInv, gato_utils.cuh:476); the pivot row is
+        // saved already scaled, the pivot column already multiplied by 1/pv
+        const T pvinv = (T)1 / A[p + p * n];
         for (int i = lane; i < n; i += WAVE) {
-            colv[i] = A[i + p * n];
+            colv[i] = A[i + p * n] * pvinv;
             rowA[i] = A[p + i * n];
             rowI[i] = Ainv[p + i * n];
         }
@@ -81,10 +91,10 @@ __device__ void gj_inverse(T *A, T *Ainv, T *tmp, int lane)
         for (int e = lane; e < n * n; e += WAVE) {
             const int r = e % n, c = e / n;
             if (r == p) {
-                A[e] /= pv;
-                Ainv[e] /= pv;
+                A[e] = rowA[c] * pvinv;
+                Ainv[e] = rowI[c] * pvinv;
             } else {
-                const T f = colv[r] / pv;
+                const T f = colv[r];
                 A[e] -= f * rowA[c];
                 Ainv[e] -= f * rowI[c];
             }
@@ -316,11 +326,19 @@ template <typename T, int S, int C>
 int launch_convert(const Dims &d, const int *G_row, const int *G_col, const T *G_val, const int *C_row,
                    const int *C_col, const T *C_val, T rho, T *Gd, T *Cd, hipStream_t st)
 {
-    GATO_HIP_CHECK(hipMemsetAsync(Gd, 0, d.g_dense() * sizeof(T), st));
-    if (d.c_dense()) GATO_HIP_CHECK(hipMemsetAsync(Cd, 0, d.c_dense() * sizeof(T), st));
-    const long long rows = (long long)d.N() + (long long)d.sk();
+    // one memset when the two outputs sit back to back in the solver's arena (they do in gato_linsys_device)
+    const char *g_end = (const char *)(Gd + d.g_dense());
+    const char *c_end = (const char *)(Cd + d.c_dense());
+    if ((const char *)Cd >= g_end && (const char *)Cd - g_end <= 4096 && d.c_dense()) {
+        GATO_HIP_CHECK(hipMemsetAsync(Gd, 0, (size_t)(c_end - (const char *)Gd), st));
+    } else {
+        GATO_HIP_CHECK(hipMemsetAsync(Gd, 0, d.g_dense() * sizeof(T), st));
+        if (d.c_dense()) GATO_HIP_CHECK(hipMemsetAsync(Cd, 0, d.c_dense() * sizeof(T), st));
+    }
+    const long long work = ((long long)d.N() + (long long)d.sk()) * 32;
     const int threads = 256;
-    const int blocks = (int)((rows + threads - 1) / threads < 2048 ? (rows + threads - 1) / threads : 2048);
+    const long long want = (work + threads - 1) / threads;
+    const int blocks = (int)(want < 4096 ? want : 4096);
     hipLaunchKernelGGL((convert_kernel<T, S, C>), dim3(blocks), dim3(threads), 0, st, G_row, G_col, G_val, C_row,
                        C_col, C_val, d.K, rho, Gd, Cd);
     GATO_HIP_CHECK(hipGetLastError());

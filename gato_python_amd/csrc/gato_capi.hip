@@ -234,9 +234,9 @@ extern "C" int gato_solver_create(int S, int C, int K, int dtype, int device, ga
     const int max_groups = 4096;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 8); return o; };
-    // slots first: they are memset before every launch (keep them at the allocation start)
-    const size_t o_slots = take((size_t)2 * 256 * pcg_slot_granules(S, (int)e) * 8);
+    // status block first, granules right behind it: one memset re-initialises both before a launch
     const size_t o_status = take(64);
+    const size_t o_slots = take((size_t)2 * 256 * pcg_slot_granules(S, (int)e) * 8);
     const size_t o_G = take(d.g_dense() * e), o_C = take(d.c_dense() * e), o_Gi = take(d.g_dense() * e);
     const size_t o_S = take(d.bd() * e), o_P = take(d.bd() * e), o_gam = take(d.sk() * e);
     const size_t o_lam = take(d.sk() * e), o_dz = take(d.N() * e);

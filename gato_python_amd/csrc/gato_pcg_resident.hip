@@ -216,7 +216,10 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     gi32 *g_status = (gi32 *)a.status;
     const unsigned long long t_limit = a.timeout_ticks;
 
-    if (tid == 0) s_abort = 0;
+    if (tid == 0) {
+        s_abort = 0;
+        if (W == 1) *a.status = 0;
+    }
     for (int i = tid; i < 2 * (Cfg::MAXK + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = (T)0;
     __syncthreads();
 
@@ -447,8 +450,17 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
         return GATO_EINVAL;
     }
     const size_t slot_bytes = (size_t)2 * a.groups * pcg_slot_granules(S, (int)sizeof(T)) * 8;
-    if (a.groups > 1) GATO_HIP_CHECK(hipMemsetAsync(a.slots, 0, slot_bytes, st));
-    GATO_HIP_CHECK(hipMemsetAsync(a.status, 0, sizeof(int), st));
+    // hand-off state is re-initialised before every launch (one memset node: the status word sits right
+    // behind the granules in the solver arena); a single workgroup polls nothing and clears the word itself
+    if (a.groups > 1) {
+        const char *st0 = (const char *)a.status;
+        if ((const char *)a.slots == st0 + 256) {
+            GATO_HIP_CHECK(hipMemsetAsync(a.status, 0, 256 + slot_bytes, st));
+        } else {
+            GATO_HIP_CHECK(hipMemsetAsync(a.slots, 0, slot_bytes, st));
+            GATO_HIP_CHECK(hipMemsetAsync(a.status, 0, sizeof(int), st));
+        }
+    }
     if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
     if constexpr (SINGLE_T > 0) {
         if (single_lds) {
