@@ -39,6 +39,8 @@ WORKLOADS = {
     "iiwa_14_7_k4096_f32": (14, 7, 4096, np.float32, "configs[3] on one GPU"),
     "iiwa_14_7_k4096_f64": (14, 7, 4096, np.float64, "configs[3] on one GPU, fp64"),
     "s32_c16_k1024_f32": (32, 16, 1024, np.float32, "configs[4]"),
+    # beyond register residency: the streaming kernel, genuinely HBM-bound (matrices 1.2 GB > 256 MB Infinity Cache)
+    "iiwa_14_7_k131072_f32": (14, 7, 131072, np.float32, "K beyond residency, streaming kernel (HBM-roofline run)"),
 }
 MAX_ITERS = 100
 
@@ -51,7 +53,18 @@ def dtype_name(dt):
     return "f64" if np.dtype(dt) == np.float64 else "f32"
 
 
-def run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20):
+def run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, max_iters=None):
+    global MAX_ITERS
+    saved = MAX_ITERS
+    if max_iters is not None:
+        MAX_ITERS = max_iters
+    try:
+        return _run_single(name, steps, warmup, torch, pcg_mode, pcg_reps)
+    finally:
+        MAX_ITERS = saved
+
+
+def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20):
     from gato_python_amd import synth
     from gato_python_amd.solver import Solver
     S, C, K, dt, _ = WORKLOADS[name]
@@ -94,7 +107,7 @@ def run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20):
         workload=name, S=S, C=C, K=K, dtype=dtype_name(dt),
         iters_per_s=MAX_ITERS * steps / dt_s, ms_per_step=1e3 * dt_s / steps,
         pcg_launch_ms=pcg_ms, pcg_launch_ms_min=float(np.min(ms)),
-        pcg_iters_per_s=MAX_ITERS / (pcg_ms * 1e-3),
+        pcg_iters_per_s=MAX_ITERS / (pcg_ms * 1e-3), pcg_us_per_iter=1e3 * pcg_ms / MAX_ITERS,
         pcg_mode={1: "resident", 2: "streaming"}.get(sol.get_option("last_mode")),
         pcg_groups=sol.get_option("last_groups"), pcg_threads=sol.get_option("last_threads"),
         algorithmic_bytes_per_launch=bytes_launch,
@@ -185,7 +198,14 @@ def main():
                       "s32_c16_k1024_f32"):
             r, _ = run_single(other, max(10, args.steps // 10), 3, torch)
             r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
+            r["hbm_bytes_per_launch_pmc"] = committed_traffic(other)
             sweep.append(r)
+        # HBM-bound regime: 20 iterations per solve keep the run short (237 us per iteration)
+        r, _ = run_single("iiwa_14_7_k131072_f32", 3, 1, torch, pcg_reps=5, max_iters=20)
+        r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
+        r["max_iters"] = 20
+        r["hbm_bytes_per_launch_pmc"] = committed_traffic("iiwa_14_7_k131072_f32")
+        sweep.append(r)
         out["sweep"] = sweep
     print(json.dumps(out))
 

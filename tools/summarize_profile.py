@@ -78,5 +78,23 @@ for name, (prefix, K) in WL.items():
                                       "fetched bytes (MI355X_MICROARCH.md, HBM section); calibrated here on the K=50 "
                                       "launches, where 2 x FETCH_SIZE equals the S + Pinv bytes read once. launches=%d"
                                       % len(fetch[key]))
+# streaming PCG (K = 131072): traffic of one whole gato_pcg call = sum over its launches (init + 2 per iteration)
+def total(acc, prefix):
+    return sum(sum(v) for k, v in acc.items() if k[0].startswith(prefix))
+
+
+def count(acc, prefix):
+    return sum(len(v) for k, v in acc.items() if k[0].startswith(prefix))
+
+
+n_step = count(fetch, "stream_step_kernel<float, 14")
+if n_step:
+    f_kb, w_kb = total(fetch, "stream_step_kernel<float, 14"), total(write, "stream_step_kernel<float, 14")
+    traffic["iiwa_14_7_k131072_f32"] = dict(
+        kernel="stream_step_kernel<float, 14, *> (all phases)", launches=n_step,
+        fetch_size_kb_per_step_launch=f_kb / n_step, write_size_kb_per_step_launch=w_kb / max(count(write, "stream_step_kernel<float, 14"), 1),
+        hbm_bytes_per_launch=(2 * f_kb / n_step + w_kb / max(count(write, "stream_step_kernel<float, 14"), 1)) * 1024 * 41,
+        note="per gato_pcg call of 20 iterations = 41 stream_step launches; (2 x FETCH_SIZE + WRITE_SIZE) averaged per "
+             "launch x 41; 16-B-per-lane LDS-DMA stream: the x2 FETCH_SIZE correction applies")
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(out)))
