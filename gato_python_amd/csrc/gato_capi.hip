@@ -107,7 +107,7 @@ struct gato_solver {
     char *in_arena;
     size_t in_bytes;
     int last_groups, last_threads, last_mode;
-    int time_pcg, stamp_pcg, ablate, no_single_lds;
+    int time_pcg, stamp_pcg, ablate, no_single_lds, true_warm_start;
     hipEvent_t ev_pcg0, ev_pcg1;
     // knot-sharded PCG state (gato_shard_pcg_*)
     struct {
@@ -298,6 +298,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "stamp_pcg")) s->stamp_pcg = value;
     else if (!strcmp(name, "ablate")) s->ablate = value;
     else if (!strcmp(name, "no_single_lds")) s->no_single_lds = value;
+    else if (!strcmp(name, "true_warm_start")) s->true_warm_start = value;
     else if (!strcmp(name, "time_pcg")) {
         s->time_pcg = value;
         if (value && !s->ev_pcg0) {
@@ -416,6 +417,7 @@ extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, con
         }
         PcgLaunch a;
         a.S_bd = d_S; a.P_bd = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda;
+        a.lambda0 = s->true_warm_start ? d_lambda : nullptr;      // in place: every lane reads its lambda0 first
         a.K = s->d.K; a.max_iters = max_iters; a.exit_tol = exit_tol;
         a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
         a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
@@ -429,6 +431,7 @@ extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, con
         return s->ops->pcg_resident(a, st);
     }
     s->last_mode = GATO_PCG_STREAMING; s->last_groups = 0; s->last_threads = 0;
+    s->sw.warm_start = s->true_warm_start;
     if (s->time_pcg) GATO_HIP_CHECK(hipEventRecord(s->ev_pcg0, st));
     int rc = s->ops->pcg_streaming(s->d, d_S, d_Pinv, d_gamma, d_lambda, exit_tol, max_iters,
                                    d_iters ? d_iters : s->iters, s->sw, st);

@@ -86,6 +86,7 @@ struct Dims {
 struct PcgLaunch {
     const void *S_bd, *P_bd, *gamma;
     void *lambda;
+    const void *lambda0;         // initial guess (true warm start, r0 = gamma - S lambda0) or nullptr = cold start
     int K;
     int max_iters;
     double exit_tol;
@@ -141,6 +142,7 @@ struct PcgStreamWork {
     void *scalars;                 // final eta (double)
     int *done;                     // device flag
     int max_groups;
+    int warm_start;                // lambda holds an initial guess on entry
 };
 // One launch of the streaming PCG on a shard of block rows (see gato_pcg_stream.hip).
 struct StreamStep {

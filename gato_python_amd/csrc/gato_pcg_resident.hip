@@ -349,6 +349,33 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         if constexpr (NL > 0) return row_times_window_lds<T, S, SP, NL, MAXT>(pm, ptail, tid, xw);
         else return row_times_window<T, S, SP>(pm, xw);
     };
+    // ---- optional true warm start (the reference accepts input_lambda but restarts from
+    // zero, gato_pcg.cuh:303):  lambda = lambda0,  r = gamma - S lambda0.  The ghost blocks of r then come from the
+    // neighbours through the ordinary hand-off.
+    if (a.lambda0) {
+        const T *__restrict__ dL0 = static_cast<const T *>(a.lambda0);
+        lam = active ? dL0[(size_t)k * S + r_] : (T)0;
+        if (active) xs[0][(j + 1) * SP + r_] = lam;
+        if (tid < S) {
+            if (has_left) xs[0][tid] = dL0[(size_t)(k0 - 1) * S + tid];
+        } else if (tid < 2 * S) {
+            if (has_right) xs[0][(nk + 1) * SP + (tid - S)] = dL0[(size_t)(k0 + nk) * S + (tid - S)];
+        }
+        __syncthreads();
+        r -= row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
+        __syncthreads();
+        if (active) xs[1][(j + 1) * SP + r_] = r;
+        if (W > 1) {
+            T dummy;
+            allreduce_and_halo(r, (T)0, dummy);
+            if (tid < S) xs[1][tid] = gh[0][tid];
+            else if (tid < 2 * S) xs[1][(nk + 1) * SP + (tid - S)] = gh[1][tid - S];
+        }
+        // the p window is rebuilt from r~ below; clear what lambda0 left in its ghost slots
+        if (tid < S) xs[0][tid] = (T)0;
+        else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = (T)0;
+        __syncthreads();
+    }
     rt = pinv_times(&xs[1][j * SP]);
     allreduce_and_halo(rt, r * rt, eta);
     if (!aborted) {

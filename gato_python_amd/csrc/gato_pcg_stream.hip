@@ -156,7 +156,7 @@ __global__ __launch_bounds__((StreamCfg<T, S>::THREADS)) void stream_step_kernel
                 const long long gi = (long long)(kt - 1) * S + i;
                 if (gi >= 0 && gi < nrows) {
                     if (PHASE == 0 || use_old) pa[m] = a_old[gi];
-                    if (PHASE != 0) pb[m] = b[gi];
+                    if (PHASE != 0 || b) pb[m] = b[gi];
                 } else {
                     const bool left = gi < 0;
                     if (left ? !a.first_global : !a.last_global) {
@@ -164,7 +164,7 @@ __global__ __launch_bounds__((StreamCfg<T, S>::THREADS)) void stream_step_kernel
                         const T *ga = (const T *)(left ? a.gh_a_left : a.gh_a_right);
                         const T *gb = (const T *)(left ? a.gh_b_left : a.gh_b_right);
                         if (PHASE == 0 || use_old) pa[m] = ga[e];
-                        if (PHASE != 0) pb[m] = gb[e];
+                        if (PHASE != 0 || gb) pb[m] = gb[e];
                     }
                 }
             }
@@ -174,6 +174,7 @@ __global__ __launch_bounds__((StreamCfg<T, S>::THREADS)) void stream_step_kernel
             pp = p_cur[gi];
             pl = lam[gi];
         }
+
     };
 
     T part = (T)0;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__((StreamCfg<T, S>::THREADS)) void stream_step_kernel
             const int i = tid + m * THREADS;
             if (i < (nk + 2) * S) {
                 T x;
-                if (PHASE == 0) x = pa[m];                                       // r = gamma
+                if (PHASE == 0) x = pa[m] - pb[m];                               // r = gamma (- S lambda0 when warm)
                 else if (PHASE == 1) x = pb[m] + coef * pa[m];                   // p = r~ + beta p   (pa = 0 at it 0)
                 else x = pa[m] - coef * pb[m];                                   // r = r - alpha upsilon
                 const long long gi = (long long)(kt - 1) * S + i;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__((StreamCfg<T, S>::THREADS)) void stream_step_kernel
             y[gi] = acc;
             part += xv[SPX + r] * acc;
             if (PHASE == 2) lam[gi] = my_l + coef * my_p;                        // gato_pcg.cuh:150-153
-            else if (PHASE == 0) lam[gi] = (T)0;
+            else if (PHASE == 0) lam[gi] = p_cur ? p_cur[gi] : (T)0;               // lambda = lambda0 or 0
         }
     }
     // one slot per workgroup
@@ -338,6 +339,7 @@ int launch_pcg_streaming(const Dims &d, const T *Sbd, const T *Pbd, const T *gam
                          int max_iters, int *iters, const PcgStreamWork &w, hipStream_t st)
 {
     const int K = d.K;
+    const bool warm = w.warm_start != 0;
     const int grid = stream_grid<T, S>(K, w.max_groups);
     // six S*K vectors, consecutive in the workspace: r and p ping-pong pairs (the fused AXPY reads the old
     // vector of neighbouring knots while the new one is written), upsilon, r~.
@@ -356,8 +358,17 @@ int launch_pcg_streaming(const Dims &d, const T *Sbd, const T *Pbd, const T *gam
     a.first_global = a.last_global = 1;
     a.num_n = a.den_n = grid; a.num_stride = a.den_stride = 1;
     int rc;
-    // init: r0 = gamma, r~ = Pinv r0, eta slots -> pb(0)
-    a.M = Pbd; a.a_old = gamma; a.b = nullptr; a.a_new = r[0]; a.y = rt; a.lam = lambda; a.part_out = pb(0); a.it = 0;
+    if (warm) {
+        // true warm start: upsilon = S lambda0 with the init kernel used as a plain block-tridiagonal product
+        // (its lambda/a_new outputs go to scratch), then r0 = gamma - upsilon, lambda = lambda0
+        a.M = Sbd; a.a_old = lambda; a.b = nullptr; a.a_new = r[1]; a.y = ups; a.lam = p[1]; a.p_cur = nullptr;
+        a.part_out = PA; a.it = 0;
+        if ((rc = launch_stream_step<T, S>(0, a, grid, st))) return rc;
+        GATO_HIP_CHECK(hipMemcpyAsync(p[0], lambda, sk * sizeof(T), hipMemcpyDeviceToDevice, st));   // lambda0 snapshot
+    }
+    // init: r0 = gamma (- S lambda0), r~ = Pinv r0, eta slots -> pb(0)
+    a.M = Pbd; a.a_old = gamma; a.b = warm ? ups : nullptr; a.a_new = r[0]; a.y = rt; a.lam = lambda;
+    a.p_cur = warm ? p[0] : nullptr; a.part_out = pb(0); a.it = 0;
     if ((rc = launch_stream_step<T, S>(0, a, grid, st))) return rc;
     for (int it = 0; it < max_iters; ++it) {
         const int ri = it & 1, pi = it & 1;

@@ -92,6 +92,7 @@ class Solver:
         return Pb
 
     def pcg(self, Sb, Pb, gamma, exit_tol, max_iters, lam=None, iters=None, check=True):
+        """lam: output; with set_option("true_warm_start", 1) it is also the initial guess (in place)."""
         lam = self.new(self.sizes["sk"]) if lam is None else lam
         iters = self.new(1, torch.int32) if iters is None else iters
         _lib.check(_lib.lib().gato_pcg(self._h, _ptr(Sb), _ptr(Pb), _ptr(gamma), _ptr(lam), float(exit_tol),

@@ -64,7 +64,10 @@ int gato_solver_destroy(gato_solver *s);
  * which: 0 G_dense, 1 C_dense, 2 Ginv_dense, 3 S, 4 Pinv, 5 gamma, 6 lambda, 7 dz, 8 iters(int) */
 void *gato_solver_buffer(gato_solver *s, int which);
 /* Options: pcg_mode (GATO_PCG_*), pcg_threads (0 = auto; threads per workgroup of the resident
- * kernel), pcg_groups (0 = auto; workgroups of the resident kernel). */
+ * kernel), pcg_groups (0 = auto; workgroups of the resident kernel), true_warm_start (0 = the
+ * reference's behaviour: lambda restarts from zero, gato_pcg.cuh:303; 1 = d_lambda of gato_pcg /
+ * gato_linsys_device is read as the initial guess, r0 = gamma - S lambda0), time_pcg (record
+ * hipEvents around the PCG launch), no_single_lds / stamp_pcg / ablate (diagnostics). */
 int gato_solver_set_option(gato_solver *s, const char *name, int value);
 int gato_solver_get_option(gato_solver *s, const char *name, int *value);
 

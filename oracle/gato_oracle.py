@@ -211,12 +211,17 @@ def bt_matvec(L, M, R, x):
 # --------------------------------------------------------------------------------------------
 # A5: PCG, K4 semantics                           (src/gato_pcg.cuh:270-439)
 # --------------------------------------------------------------------------------------------
-def pcg(S_bd, Pinv_bd, gamma, S, K, exit_tol, max_iters, return_history=False):
+def pcg(S_bd, Pinv_bd, gamma, S, K, exit_tol, max_iters, return_history=False, lam0=None):
+    """lam0: optional initial guess (true warm start, r0 = gamma - S lam0) - an extension; the reference resets
+    lambda to zero whatever it is given (D5)."""
     dtype = S_bd.dtype
     Sl, Sm, Sr = unpack_bd(S_bd, S, K)
     Pl, Pm, Pr = unpack_bd(Pinv_bd, S, K)
     lam = np.zeros((K, S), dtype)                     # :303 (lambda reset to 0, D5)
     r = np.asarray(gamma, dtype).reshape(K, S).copy() # :301
+    if lam0 is not None:
+        lam = np.asarray(lam0, dtype).reshape(K, S).copy()
+        r = r - bt_matvec(Sl, Sm, Sr, lam)
     rt = bt_matvec(Pl, Pm, Pr, r)                     # :316-318
     p = rt.copy()                                     # :322-325
     eta = dtype.type(np.sum(r * rt, dtype=dtype))     # :327-335

@@ -290,3 +290,39 @@ print('Test passed')
     r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "Test passed" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     assert "first run PCG terminated in " in r.stdout and "avg time:" in r.stdout
+
+
+@pytest.mark.parametrize("S,C,K,dt,opts", [(14, 7, 50, np.float64, {}), (14, 7, 50, np.float32, {}),
+                                           (14, 7, 300, np.float64, {}), (2, 1, 40, np.float64, dict(pcg_threads=64)),
+                                           (14, 7, 300, np.float64, dict(pcg_mode=_lib.PCG_STREAMING)),
+                                           (32, 16, 40, np.float32, dict(pcg_mode=_lib.PCG_STREAMING))])
+def test_true_warm_start(S, C, K, dt, opts):
+    """opt-in real warm start r0 = gamma - S lambda0 (the default stays the reference's
+    no-op, D5).  Checked against the numpy restatement with the same lambda0."""
+    s = synth.make_system(S, C, K, seed=17)
+    out = o.linsys_solve(*s.csr_args(), S, C, K, 1e-30, 6, s.rho, dtype=dt, return_all=True)    # 6 iterations in
+    lam0 = out["lam"]
+    f64 = dt == np.float64
+    tol = 1e-9 if f64 else 1e-4
+    lam_w, it_w = o.pcg(out["S"], out["Pinv"], out["gamma"], S, K, tol, 300, lam0=lam0)
+    lam_c, it_c = o.pcg(out["S"], out["Pinv"], out["gamma"], S, K, tol, 300)
+    assert it_w < it_c                                              # the guess helps
+    sol = make_solver(S, C, K, dt)
+    for k, v in opts.items():
+        sol.set_option(k, v)
+    dS, dP, dg = sol.to_device(out["S"]), sol.to_device(out["Pinv"]), sol.to_device(out["gamma"])
+    # default: reference behaviour, the initial guess is ignored
+    lam = sol.to_device(lam0)
+    lam, it = sol.pcg(dS, dP, dg, tol, 300, lam=lam)
+    assert abs(int(host(it)[0]) - it_c) <= (0 if f64 else 2) and rel(host(lam), lam_c) < (1e-9 if f64 else 5e-3)
+    # opt-in: true warm start
+    sol.set_option("true_warm_start", 1)
+    lam = sol.to_device(lam0)
+    lam, it = sol.pcg(dS, dP, dg, tol, 300, lam=lam)
+    assert abs(int(host(it)[0]) - it_w) <= (0 if f64 else 2), (int(host(it)[0]), it_w)
+    assert rel(host(lam), lam_w) < (1e-9 if f64 else 5e-3)
+    # starting from the converged solution: exits at once
+    lam = sol.to_device(lam_w)
+    lam2, it = sol.pcg(dS, dP, dg, tol * 1e4, 300, lam=lam)
+    assert int(host(it)[0]) <= 1 and rel(host(lam2), lam_w) < (1e-5 if f64 else 5e-3)   # one more step is taken before the test
+    sol.close()
