@@ -11,7 +11,11 @@
 
 // (S, C) instantiations compiled in.  The reference is compiled for exactly one triple
 // (CMakeLists.txt:18); here K is a runtime value and (S, C) picks one of these.
-#define GATO_SHAPES(X) X(2, 1) X(14, 7) X(32, 16)
+// Add shapes at build time with  make EXTRA_SHAPES="X(12,6) X(6,3)"  (S <= 32, S even, C <= S).
+#ifndef GATO_EXTRA_SHAPES
+#define GATO_EXTRA_SHAPES(X)
+#endif
+#define GATO_SHAPES(X) X(2, 1) X(14, 7) X(32, 16) GATO_EXTRA_SHAPES(X)
 
 namespace gato {
 

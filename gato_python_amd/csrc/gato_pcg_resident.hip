@@ -436,7 +436,13 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     }
 }
 
-template <typename T, int S> struct MaxThreads;
+// Generic rule for shapes added at build time: VGPRs per lane ~ matrix rows (6S words, x2 for fp64) + the
+// operand window the compiler keeps in flight (3S words) + ~40; the specialisations below are the measured ones.
+template <typename T, int S> struct MaxThreads {
+    static constexpr int regs = (6 * S + 3 * S) * (int)(sizeof(T) / 4) + 40;
+    static constexpr int v = regs <= 128 ? 1024 : regs <= 168 ? 768 : regs <= 256 ? 512 : 256;
+    static_assert(regs <= 512, "STATE_SIZE too large for the register-resident PCG");
+};
 // VGPR budget: 3S*2 matrix registers per lane (x2 for fp64).  launch bound -> registers per lane:
 // 1024 threads -> 128, 768 -> 168, 512 -> 256, 256 -> 512 (MI355X register file: 512 per lane per SIMD).
 // Chosen so that the matrix rows plus the 3S-wide operand window stay in registers without spilling.
