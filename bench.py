@@ -117,6 +117,43 @@ def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20):
     return res, sysm
 
 
+def run_batched(S, C, K, dt, B, steps, warmup, torch):
+    """B independent systems per call (one workgroup per system in the PCG launch)."""
+    from gato_python_amd import synth
+    from gato_python_amd.solver import Solver
+    base = synth.make_system(S, C, K, seed=0)
+    systems = [base] * B                       # same values in every system: timing only
+    sol = Solver(S, C, K, dt, batch=B)
+    dev = sol.upload_batch(systems)
+    lam, dz = sol.new(B * S * K), sol.new(B * sol.N)
+    iters = sol.new(B, torch.int32)
+    step = lambda: sol.linsys_batched(*dev, 0.0, MAX_ITERS, base.rho, lam, dz, iters)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    sol.set_option("time_pcg", 1)
+    bufs = [sol.buffer_ptr(i) for i in (3, 4, 5)]
+    ms = []
+    for i in range(8):
+        sol.pcg(bufs[0], bufs[1], bufs[2], 0.0, MAX_ITERS, lam=lam, iters=iters, check=False)
+        ms.append(sol.pcg_last_ms())
+    pcg_ms = float(np.mean(ms[2:]))
+    w = np.dtype(dt).itemsize
+    bytes_launch = b_iter(S, K, w) * MAX_ITERS * B
+    r = dict(workload=f"batched_{B}x_{S}_{C}_k{K}_{dtype_name(dt)}", S=S, C=C, K=K, dtype=dtype_name(dt), batch=B,
+             iters_per_s=MAX_ITERS * B * steps / el, ms_per_step=1e3 * el / steps, pcg_launch_ms=pcg_ms,
+             pcg_iters_per_s=MAX_ITERS * B / (pcg_ms * 1e-3), pcg_mode="resident, one workgroup per system",
+             algorithmic_bytes_per_launch=bytes_launch, achieved_gbs=bytes_launch / (pcg_ms * 1e-3) / 1e9)
+    r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
+    sol.close()
+    return r
+
+
 def cpu_baseline(sysm, dt, budget_s=10.0):
     """The C restatement (oracle/, test infrastructure) timed on the host as the reported CPU baseline."""
     from oracle import c_oracle as co
@@ -200,6 +237,9 @@ def main():
             r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
             r["hbm_bytes_per_launch_pmc"] = committed_traffic(other)
             sweep.append(r)
+        # batches of independent systems: throughput mode of the K=50 shape
+        sweep.append(run_batched(14, 7, 50, np.float64, 512, 10, 2, torch))
+        sweep.append(run_batched(14, 7, 50, np.float32, 512, 10, 2, torch))
         # HBM-bound regime: 20 iterations per solve keep the run short (237 us per iteration)
         r, _ = run_single("iiwa_14_7_k131072_f32", 3, 1, torch, pcg_reps=5, max_iters=20)
         r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS

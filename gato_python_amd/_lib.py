@@ -21,7 +21,8 @@ ERRORS = {-1: "EINVAL", -2: "ESHAPE", -3: "EHIP", -4: "ENODEV", -5: "ETIMEOUT"}
 # Every symbol include/gato_hip.h declares (tests check the .so exports all of them).
 SYMBOLS = [
     "gato_last_error", "gato_version", "gato_num_shapes", "gato_shape", "gato_device_info",
-    "gato_infer_shape", "gato_solver_create", "gato_solver_destroy", "gato_solver_buffer",
+    "gato_infer_shape", "gato_solver_create", "gato_solver_create_batched", "gato_linsys_device_batched",
+    "gato_solver_destroy", "gato_solver_buffer",
     "gato_solver_set_option", "gato_solver_get_option", "gato_convert", "gato_form_schur",
     "gato_form_ss", "gato_pcg", "gato_pcg_status", "gato_pcg_last_ms", "gato_compute_dz", "gato_linsys_device",
     "gato_linsys_solve_f32", "gato_linsys_solve_f64",
@@ -55,6 +56,8 @@ def lib() -> ct.CDLL:
         L.gato_solver_buffer.restype = ct.c_void_p
         vp, ip, i, d = ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_double
         L.gato_solver_create.argtypes = [i, i, i, i, i, ct.POINTER(ct.c_void_p)]
+        L.gato_solver_create_batched.argtypes = [i, i, i, i, i, i, ct.POINTER(ct.c_void_p)]
+        L.gato_linsys_device_batched.argtypes = [vp, ip, ip, vp, i, ip, ip, vp, i, vp, vp, d, i, d, vp, vp, vp, vp]
         L.gato_solver_destroy.argtypes = [vp]
         L.gato_solver_buffer.argtypes = [vp, i]
         L.gato_solver_set_option.argtypes = [vp, ct.c_char_p, i]

@@ -26,10 +26,12 @@ template <typename T, int S, int C>
 __global__ void convert_kernel(const int *__restrict__ G_row, const int *__restrict__ G_col,
                                const T *__restrict__ G_val, const int *__restrict__ C_row,
                                const int *__restrict__ C_col, const T *__restrict__ C_val, int K, T rho,
-                               T *__restrict__ Gd, T *__restrict__ Cd)
+                               T *__restrict__ Gd, T *__restrict__ Cd, BatchStride bs)
 {
     constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C;
-    constexpr int SLOTS = 32;                                   // >= S + C + 1 for the compiled shapes' C rows
+    constexpr int SLOTS = 32;
+    G_val += blockIdx.y * bs.nnzG; C_val += blockIdx.y * bs.nnzC;      // batch: shared structure, own values
+    Gd += blockIdx.y * bs.g; Cd += blockIdx.y * bs.c;                                   // >= S + C + 1 for the compiled shapes' C rows
     const int N = n * K - C;
     const int SK = S * K;
     const long long total = (long long)(N + SK) * SLOTS;
@@ -140,9 +142,11 @@ __device__ __forceinline__ void mTv(T *out, const T *A, const T *x, int lane)
 
 // ---- A2a: invert every Q_k and R_k once -------------------------------------------------------
 template <typename T, int S, int C>
-__global__ __launch_bounds__(WAVE) void invert_G_kernel(const T *__restrict__ Gd, T *__restrict__ Ginv, int K)
+__global__ __launch_bounds__(WAVE) void invert_G_kernel(const T *__restrict__ Gd, T *__restrict__ Ginv, int K,
+                                                        BatchStride bs)
 {
     constexpr int SS = S * S, CC = C * C;
+    Gd += blockIdx.y * bs.g; Ginv += blockIdx.y * bs.g;
     __shared__ T A[SS], Ai[SS], tmp[3 * S];
     const int lane = threadIdx.x;
     for (int k = blockIdx.x; k < K; k += gridDim.x) {
@@ -167,9 +171,11 @@ template <typename T, int S, int C>
 __global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, const T *__restrict__ Ginv,
                                                      const T *__restrict__ Cd, const T *__restrict__ g,
                                                      const T *__restrict__ c, int K, T *__restrict__ Sbd,
-                                                     T *__restrict__ Pbd, T *__restrict__ gamma)
+                                                     T *__restrict__ Pbd, T *__restrict__ gamma, BatchStride bs)
 {
     constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C;
+    Gd += blockIdx.y * bs.g; Ginv += blockIdx.y * bs.g; Cd += blockIdx.y * bs.c; g += blockIdx.y * bs.n;
+    c += blockIdx.y * bs.sk; Sbd += blockIdx.y * bs.bd; Pbd += blockIdx.y * bs.bd; gamma += blockIdx.y * bs.sk;
     __shared__ T sA[SS], sB[SC], sQim[SS], sQik[SS], sRim[CC], sPhi[SS], sBR[SC], sTh[SS], sTmp[SS];
     __shared__ T sq[2 * S + C], sv[3 * S], stmp[3 * S];
     const int lane = threadIdx.x;
@@ -238,9 +244,10 @@ __global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, c
 
 // ---- A3: symmetric stair (gato_schur.cuh:497-649) ------------------------------------------------
 template <typename T, int S>
-__global__ __launch_bounds__(WAVE) void ss_kernel(const T *__restrict__ Sbd, T *__restrict__ Pbd, int K)
+__global__ __launch_bounds__(WAVE) void ss_kernel(const T *__restrict__ Sbd, T *__restrict__ Pbd, int K, BatchStride bs)
 {
     constexpr int SS = S * S;
+    Sbd += blockIdx.y * bs.bd; Pbd += blockIdx.y * bs.bd;
     __shared__ T sPm[SS], sX[SS], sPn[SS], sT[SS], sO[SS];
     const int lane = threadIdx.x;
     for (int k = blockIdx.x; k < K; k += gridDim.x) {
@@ -276,9 +283,11 @@ __global__ __launch_bounds__(WAVE) void ss_kernel(const T *__restrict__ Sbd, T *
 template <typename T, int S, int C>
 __global__ __launch_bounds__(WAVE) void dz_kernel(const T *__restrict__ Ginv, const T *__restrict__ Cd,
                                                   const T *__restrict__ g, const T *__restrict__ lambda,
-                                                  int K, T *__restrict__ dz)
+                                                  int K, T *__restrict__ dz, BatchStride bs)
 {
     constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C;
+    Ginv += blockIdx.y * bs.g; Cd += blockIdx.y * bs.c; g += blockIdx.y * bs.n; lambda += blockIdx.y * bs.sk;
+    dz += blockIdx.y * bs.n;
     __shared__ T sQi[SS], sA[SS], sRi[CC > 0 ? CC : 1], sB[SC > 0 ? SC : 1], sl[2 * S], st[S + C], sg[S + C];
     const int lane = threadIdx.x;
     for (int k = blockIdx.x; k < K; k += gridDim.x) {
@@ -327,20 +336,20 @@ int launch_convert(const Dims &d, const int *G_row, const int *G_col, const T *G
                    const int *C_col, const T *C_val, T rho, T *Gd, T *Cd, hipStream_t st)
 {
     // one memset when the two outputs sit back to back in the solver's arena (they do in gato_linsys_device)
-    const char *g_end = (const char *)(Gd + d.g_dense());
-    const char *c_end = (const char *)(Cd + d.c_dense());
+    const char *g_end = (const char *)(Gd + d.g_dense() * d.B);
+    const char *c_end = (const char *)(Cd + d.c_dense() * d.B);
     if ((const char *)Cd >= g_end && (const char *)Cd - g_end <= 4096 && d.c_dense()) {
         GATO_HIP_CHECK(hipMemsetAsync(Gd, 0, (size_t)(c_end - (const char *)Gd), st));
     } else {
-        GATO_HIP_CHECK(hipMemsetAsync(Gd, 0, d.g_dense() * sizeof(T), st));
-        if (d.c_dense()) GATO_HIP_CHECK(hipMemsetAsync(Cd, 0, d.c_dense() * sizeof(T), st));
+        GATO_HIP_CHECK(hipMemsetAsync(Gd, 0, d.g_dense() * d.B * sizeof(T), st));
+        if (d.c_dense()) GATO_HIP_CHECK(hipMemsetAsync(Cd, 0, d.c_dense() * d.B * sizeof(T), st));
     }
     const long long work = ((long long)d.N() + (long long)d.sk()) * 32;
     const int threads = 256;
     const long long want = (work + threads - 1) / threads;
     const int blocks = (int)(want < 4096 ? want : 4096);
-    hipLaunchKernelGGL((convert_kernel<T, S, C>), dim3(blocks), dim3(threads), 0, st, G_row, G_col, G_val, C_row,
-                       C_col, C_val, d.K, rho, Gd, Cd);
+    hipLaunchKernelGGL((convert_kernel<T, S, C>), dim3(blocks, d.B), dim3(threads), 0, st, G_row, G_col, G_val, C_row,
+                       C_col, C_val, d.K, rho, Gd, Cd, batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
     return GATO_OK;
 }
@@ -351,10 +360,11 @@ template <typename T, int S, int C>
 int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const T *c, T *Sbd, T *Pbd,
                       T *gamma, T *Ginv, hipStream_t st)
 {
-    hipLaunchKernelGGL((invert_G_kernel<T, S, C>), dim3(knot_grid(d.K)), dim3(WAVE), 0, st, Gd, Ginv, d.K);
+    hipLaunchKernelGGL((invert_G_kernel<T, S, C>), dim3(knot_grid(d.K), d.B), dim3(WAVE), 0, st, Gd, Ginv, d.K,
+                       batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL((schur_kernel<T, S, C>), dim3(knot_grid(d.K)), dim3(WAVE), 0, st, Gd, Ginv, Cd, g, c, d.K,
-                       Sbd, Pbd, gamma);
+    hipLaunchKernelGGL((schur_kernel<T, S, C>), dim3(knot_grid(d.K), d.B), dim3(WAVE), 0, st, Gd, Ginv, Cd, g, c, d.K,
+                       Sbd, Pbd, gamma, batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
     return GATO_OK;
 }
@@ -362,7 +372,7 @@ int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const
 template <typename T, int S, int C>
 int launch_form_ss(const Dims &d, const T *Sbd, T *Pbd, hipStream_t st)
 {
-    hipLaunchKernelGGL((ss_kernel<T, S>), dim3(knot_grid(d.K)), dim3(WAVE), 0, st, Sbd, Pbd, d.K);
+    hipLaunchKernelGGL((ss_kernel<T, S>), dim3(knot_grid(d.K), d.B), dim3(WAVE), 0, st, Sbd, Pbd, d.K, batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
     return GATO_OK;
 }
@@ -371,7 +381,8 @@ template <typename T, int S, int C>
 int launch_compute_dz(const Dims &d, const T *Ginv, const T *Cd, const T *g, const T *lambda, T *dz,
                       hipStream_t st)
 {
-    hipLaunchKernelGGL((dz_kernel<T, S, C>), dim3(knot_grid(d.K)), dim3(WAVE), 0, st, Ginv, Cd, g, lambda, d.K, dz);
+    hipLaunchKernelGGL((dz_kernel<T, S, C>), dim3(knot_grid(d.K), d.B), dim3(WAVE), 0, st, Ginv, Cd, g, lambda, d.K, dz,
+                       batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
     return GATO_OK;
 }

@@ -199,8 +199,16 @@ extern "C" int gato_infer_shape(const int *C_row, int len_C_row, int len_g, int 
     return GATO_OK;
 }
 
+extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype, int device, gato_solver **out);
+
 extern "C" int gato_solver_create(int S, int C, int K, int dtype, int device, gato_solver **out)
 {
+    return gato_solver_create_batched(S, C, K, 1, dtype, device, out);
+}
+
+extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype, int device, gato_solver **out)
+{
+    if (B < 1) { set_error("solver_create: batch must be >= 1"); return GATO_EINVAL; }
     if (!out || K < 1 || (dtype != GATO_F32 && dtype != GATO_F64)) {
         set_error("solver_create: bad arguments (K=%d dtype=%d)", K, dtype);
         return GATO_EINVAL;
@@ -219,6 +227,7 @@ extern "C" int gato_solver_create(int S, int C, int K, int dtype, int device, ga
     gato_solver *s = new gato_solver();
     memset(s, 0, sizeof(*s));
     s->d = Dims{S, C, K};
+    s->d.B = B;
     s->dtype = dtype;
     s->device = device;
     s->esz = dtype == GATO_F32 ? 4 : 8;
@@ -237,9 +246,11 @@ extern "C" int gato_solver_create(int S, int C, int K, int dtype, int device, ga
     // status block first, granules right behind it: one memset re-initialises both before a launch
     const size_t o_status = take(64);
     const size_t o_slots = take((size_t)2 * 256 * pcg_slot_granules(S, (int)e) * 8);
-    const size_t o_G = take(d.g_dense() * e), o_C = take(d.c_dense() * e), o_Gi = take(d.g_dense() * e);
-    const size_t o_S = take(d.bd() * e), o_P = take(d.bd() * e), o_gam = take(d.sk() * e);
-    const size_t o_lam = take(d.sk() * e), o_dz = take(d.N() * e);
+    const size_t nb = (size_t)B;
+    const size_t o_G = take(d.g_dense() * e * nb), o_C = take(d.c_dense() * e * nb), o_Gi = take(d.g_dense() * e * nb);
+    const size_t o_S = take(d.bd() * e * nb), o_P = take(d.bd() * e * nb), o_gam = take(d.sk() * e * nb);
+    const size_t o_lam = take(d.sk() * e * nb), o_dz = take(d.N() * e * nb);
+    const size_t o_its = take(sizeof(int) * nb);
     const size_t o_vec = take(6 * d.sk() * e);
     const size_t o_part = take((size_t)4 * max_groups * e), o_scal = take(64 * 8), o_done = take(64);
     const size_t o_gh = take((size_t)8 * S * e);
@@ -249,7 +260,7 @@ extern "C" int gato_solver_create(int S, int C, int K, int dtype, int device, ga
     char *a = s->arena;
     s->slots = (unsigned long long *)(a + o_slots);
     s->status = (int *)(a + o_status);
-    s->iters = (int *)(a + o_status + 8);
+    s->iters = B > 1 ? (int *)(a + o_its) : (int *)(a + o_status + 8);
     s->final_eta = (double *)(a + o_status + 16);
     s->G_dense = a + o_G; s->C_dense = a + o_C; s->Ginv = a + o_Gi;
     s->Sbd = a + o_S; s->Pbd = a + o_P; s->gamma = a + o_gam; s->lambda = a + o_lam; s->dz = a + o_dz;
@@ -299,6 +310,8 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "ablate")) s->ablate = value;
     else if (!strcmp(name, "no_single_lds")) s->no_single_lds = value;
     else if (!strcmp(name, "true_warm_start")) s->true_warm_start = value;
+    else if (!strcmp(name, "batch_nnz_G")) s->d.nnzG = value;
+    else if (!strcmp(name, "batch_nnz_C")) s->d.nnzC = value;
     else if (!strcmp(name, "time_pcg")) {
         s->time_pcg = value;
         if (value && !s->ev_pcg0) {
@@ -327,6 +340,7 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "last_threads")) *value = s->last_threads;
     else if (!strcmp(name, "last_mode")) *value = s->last_mode;
     else if (!strcmp(name, "num_cus")) *value = s->num_cus;
+    else if (!strcmp(name, "batch")) *value = s->d.B;
     else if (!strcmp(name, "max_resident_knots")) *value = s->plan.max_knots_per_wg * (s->num_cus < 256 ? s->num_cus : 256);
     else { set_error("unknown option %s", name); return GATO_EINVAL; }
     return GATO_OK;
@@ -401,10 +415,9 @@ static int plan_resident(gato_solver *s, int *groups, int *threads, int *kpw)
     return 1;
 }
 
-extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
-                        double exit_tol, int max_iters, int *d_iters, void *stream)
+static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
+                   double exit_tol, int max_iters, int *d_iters, int batch, hipStream_t st)
 {
-    hipStream_t st = (hipStream_t)stream;
     int groups = 0, threads = 0, kpw = 0;
     int mode = s->pcg_mode;
     const bool fits = plan_resident(s, &groups, &threads, &kpw) != 0;
@@ -416,9 +429,11 @@ extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, con
             return GATO_EINVAL;
         }
         PcgLaunch a;
+        memset(&a, 0, sizeof(a));
         a.S_bd = d_S; a.P_bd = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda;
         a.lambda0 = s->true_warm_start ? d_lambda : nullptr;      // in place: every lane reads its lambda0 first
         a.K = s->d.K; a.max_iters = max_iters; a.exit_tol = exit_tol;
+        a.batch = batch;
         a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
         a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
         a.final_eta = s->final_eta;
@@ -437,6 +452,28 @@ extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, con
                                    d_iters ? d_iters : s->iters, s->sw, st);
     if (s->time_pcg) GATO_HIP_CHECK(hipEventRecord(s->ev_pcg1, st));
     return rc;
+}
+
+extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
+                        double exit_tol, int max_iters, int *d_iters, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int B = s->d.B;
+    if (B == 1) return pcg_one(s, d_S, d_Pinv, d_gamma, d_lambda, exit_tol, max_iters, d_iters, 1, st);
+    // batch: one workgroup per system in a single launch when a system fits one CU; otherwise system by system
+    int groups = 0, threads = 0, kpw = 0;
+    const bool fits = plan_resident(s, &groups, &threads, &kpw) != 0;
+    int *its = d_iters ? d_iters : s->iters;
+    if (fits && groups == 1 && s->pcg_mode != GATO_PCG_STREAMING)
+        return pcg_one(s, d_S, d_Pinv, d_gamma, d_lambda, exit_tol, max_iters, its, B, st);
+    const size_t e = s->esz;
+    for (int b = 0; b < B; ++b) {
+        int rc = pcg_one(s, (const char *)d_S + b * s->d.bd() * e, (const char *)d_Pinv + b * s->d.bd() * e,
+                         (const char *)d_gamma + b * s->d.sk() * e, (char *)d_lambda + b * s->d.sk() * e, exit_tol,
+                         max_iters, its + b, 1, st);
+        if (rc) return rc;
+    }
+    return GATO_OK;
 }
 
 extern "C" int gato_pcg_status(gato_solver *s, int *status)
@@ -467,6 +504,20 @@ extern "C" int gato_linsys_device(gato_solver *s, const int *d_G_row, const int 
     if ((rc = gato_form_ss(s, s->Sbd, s->Pbd, stream))) return rc;
     if ((rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream))) return rc;
     if ((rc = gato_compute_dz(s, s->Ginv, s->C_dense, d_g, lam, dz, stream))) return rc;
+    return GATO_OK;
+}
+
+extern "C" int gato_linsys_device_batched(gato_solver *s, const int *d_G_row, const int *d_G_col, const void *d_G_val,
+                                          int nnz_G, const int *d_C_row, const int *d_C_col, const void *d_C_val,
+                                          int nnz_C, const void *d_g, const void *d_c, double exit_tol, int max_iters,
+                                          double rho, void *d_lambda, void *d_dz, int *d_iters, void *stream)
+{
+    s->d.nnzG = nnz_G; s->d.nnzC = nnz_C;
+    int rc = gato_linsys_device(s, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, d_g, d_c, exit_tol, max_iters,
+                                rho, d_lambda, d_dz, stream);
+    if (rc) return rc;
+    if (d_iters && d_iters != s->iters)
+        GATO_HIP_CHECK(hipMemcpyAsync(d_iters, s->iters, sizeof(int) * s->d.B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GATO_OK;
 }
 

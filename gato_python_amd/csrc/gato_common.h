@@ -76,8 +76,13 @@ __device__ __forceinline__ T wave_sum_dpp(T v)
 }
 
 // Device layout sizes in elements (gato_defines.h:32-37, gpu_library.cu:40-45).
+// B > 1: a batch of B independent systems of the same shape and sparsity pattern.  Every
+// per-system array is stored B times back to back (system stride = its single-system size); the CSR structure
+// (indptr / indices) is shared, the value arrays have nnzG / nnzC entries per system.
 struct Dims {
     int S, C, K;
+    int B = 1;
+    int nnzG = 0, nnzC = 0;
     __host__ __device__ int n() const { return S + C; }
     __host__ __device__ size_t N() const { return (size_t)(S + C) * K - C; }
     __host__ __device__ size_t g_dense() const { return (size_t)(S * S + C * C) * K - C * C; }
@@ -85,6 +90,14 @@ struct Dims {
     __host__ __device__ size_t bd() const { return (size_t)3 * S * S * K; }
     __host__ __device__ size_t sk() const { return (size_t)S * K; }
 };
+
+struct BatchStride {
+    size_t g, c, bd, sk, n, nnzG, nnzC;     // elements per system: G_dense, C_dense, S/Pinv, gamma/lambda, g/dz, CSR values
+};
+inline BatchStride batch_stride(const Dims &d)
+{
+    return BatchStride{d.g_dense(), d.c_dense(), d.bd(), d.sk(), d.N(), (size_t)d.nnzG, (size_t)d.nnzC};
+}
 
 // ---- persistent (resident) PCG launch description ------------------------------------------
 struct PcgLaunch {
@@ -94,6 +107,7 @@ struct PcgLaunch {
     int K;
     int max_iters;
     double exit_tol;
+    int batch;                   // > 1: blockIdx.x = system index, one workgroup per system (groups must be 1)
     int knots_per_wg;            // contiguous knots owned by each workgroup (last may own fewer)
     int groups;                  // W = gridDim.x
     int threads;                 // blockDim.x (multiple of 64, >= knots_per_wg * S)

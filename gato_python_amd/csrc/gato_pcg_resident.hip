@@ -176,8 +176,11 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int nwaves = blockDim.x >> 6;
-    const int W = NL > 0 ? 1 : (int)gridDim.x;      // the LDS-tail variant is single-workgroup by construction
-    const int wg = blockIdx.x;
+    // batch > 1: one workgroup per independent system (blockIdx.x = system), no inter-workgroup traffic
+    const bool batched = a.batch > 1;
+    const int W = (NL > 0 || batched) ? 1 : (int)gridDim.x;   // the LDS-tail variant is single-workgroup by construction
+    const int wg = batched ? 0 : (int)blockIdx.x;
+    const size_t sys = batched ? blockIdx.x : 0;
     const int K = a.K;
     const int k0 = wg * a.knots_per_wg;
     const int nk = min(a.knots_per_wg, K - k0);
@@ -188,10 +191,10 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     const bool has_left = k0 > 0;
     const bool has_right = k0 + nk < K;
 
-    const T *__restrict__ dS = static_cast<const T *>(a.S_bd);
-    const T *__restrict__ dP = static_cast<const T *>(a.P_bd);
-    const T *__restrict__ dG = static_cast<const T *>(a.gamma);
-    T *__restrict__ dL = static_cast<T *>(a.lambda);
+    const T *__restrict__ dS = static_cast<const T *>(a.S_bd) + sys * 3 * S * S * K;
+    const T *__restrict__ dP = static_cast<const T *>(a.P_bd) + sys * 3 * S * S * K;
+    const T *__restrict__ dG = static_cast<const T *>(a.gamma) + sys * S * K;
+    T *__restrict__ dL = static_cast<T *>(a.lambda) + sys * S * K;
 
     // ---- load this lane's rows of S and Pinv into registers (once per solve) ----------------
     // bd layout: block-row k = [left|main|right], each S*S column-major -> element (r, c) of the
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 
     if (tid == 0) {
         s_abort = 0;
-        if (W == 1) *a.status = 0;
+        if (W == 1 && sys == 0) *a.status = 0;
     }
     for (int i = tid; i < 2 * (Cfg::MAXK + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = (T)0;
     __syncthreads();
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // zero, gato_pcg.cuh:303):  lambda = lambda0,  r = gamma - S lambda0.  The ghost blocks of r then come from the
     // neighbours through the ordinary hand-off.
     if (a.lambda0) {
-        const T *__restrict__ dL0 = static_cast<const T *>(a.lambda0);
+        const T *__restrict__ dL0 = static_cast<const T *>(a.lambda0) + sys * S * K;
         lam = active ? dL0[(size_t)k * S + r_] : (T)0;
         if (active) xs[0][(j + 1) * SP + r_] = lam;
         if (tid < S) {
@@ -426,8 +429,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     }
     if (active) dL[(size_t)k * S + r_] = lam;                                   // :433-435
     if (wg == 0 && tid == 0) {
-        *a.iters = iters;
-        if (a.final_eta) *a.final_eta = (double)eta_new;
+        a.iters[sys] = iters;
+        if (a.final_eta && sys == 0) *a.final_eta = (double)eta_new;
         if (STAMP && a.stamps) {
             for (int i = 0; i < 8; ++i) a.stamps[i] = seg[i];
             a.stamps[8] = __builtin_amdgcn_s_memtime() - t_begin;
@@ -475,6 +478,10 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
     constexpr int SINGLE_T = SingleCu<T, S>::threads;
     const bool single_lds = SINGLE_T > MAXT0 && a.groups == 1 && a.threads > MAXT0 && a.threads <= SINGLE_T;
     const int MAXT = single_lds ? SINGLE_T : MAXT0;
+    if (a.batch > 1 && a.groups != 1) {
+        set_error("pcg_resident: a batch needs one workgroup per system");
+        return GATO_EINVAL;
+    }
     if (a.threads > MAXT || a.threads % 64 != 0 || a.threads < 2 * S || a.knots_per_wg * S > a.threads ||
         a.groups < 1 || a.groups > 256 || (long long)a.groups * a.knots_per_wg < a.K ||
         (long long)(a.groups - 1) * a.knots_per_wg >= a.K) {
@@ -495,18 +502,19 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
         }
     }
     if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
+    const int nblocks = a.batch > 1 ? a.batch : a.groups;
     if constexpr (SINGLE_T > 0) {
         if (single_lds) {
             constexpr int NL = SingleCu<T, S>::nl;
-            if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, true>), dim3(1), dim3(a.threads), 0, st, a);
-            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, false>), dim3(1), dim3(a.threads), 0, st, a);
+            if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
+            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, false>), dim3(nblocks), dim3(a.threads), 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;
         }
     }
-    if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, true>), dim3(a.groups), dim3(a.threads), 0, st, a);
-    else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false>), dim3(a.groups), dim3(a.threads), 0, st, a);
+    if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
+    else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false>), dim3(nblocks), dim3(a.threads), 0, st, a);
     GATO_HIP_CHECK(hipGetLastError());
     if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
     return GATO_OK;

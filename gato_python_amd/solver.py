@@ -29,14 +29,16 @@ def _ptr(t):
 class Solver:
     """Workspace + kernels for one (STATE_SIZE, CONTROL_SIZE, KNOT_POINTS, dtype) on one GPU."""
 
-    def __init__(self, S: int, C: int, K: int, dtype=np.float32, device: int = 0):
+    def __init__(self, S: int, C: int, K: int, dtype=np.float32, device: int = 0, batch: int = 1):
         self.S, self.C, self.K = int(S), int(C), int(K)
+        self.batch = int(batch)
         self.np_dtype = np.dtype(dtype)
         self.dtype = _TORCH_DT[self.np_dtype]
         self.device = int(device)
         self._h = ct.c_void_p()
         code = _lib.GATO_F32 if self.np_dtype == np.float32 else _lib.GATO_F64
-        _lib.check(_lib.lib().gato_solver_create(self.S, self.C, self.K, code, self.device, ct.byref(self._h)))
+        _lib.check(_lib.lib().gato_solver_create_batched(self.S, self.C, self.K, self.batch, code, self.device,
+                                                         ct.byref(self._h)))
         self.n = self.S + self.C
         self.N = self.n * self.K - self.C
         self.sizes = dict(G_dense=(S * S + C * C) * K - C * C, C_dense=(S * S + S * C) * (K - 1),
@@ -115,6 +117,28 @@ class Solver:
                                                  _ptr(C_col), _ptr(C_val), _ptr(g), _ptr(c), float(exit_tol),
                                                  int(max_iters), float(rho), _ptr(lam), _ptr(dz),
                                                  self._stream()))
+
+    def linsys_batched(self, G_row, G_col, G_val, C_row, C_col, C_val, g, c, exit_tol, max_iters, rho,
+                       lam, dz, iters=None):
+        """B systems with a shared CSR structure: G_val [B*nnzG], C_val [B*nnzC], g [B*N], c [B*S*K]."""
+        nnzG, nnzC = G_val.numel() // self.batch, C_val.numel() // self.batch
+        _lib.check(_lib.lib().gato_linsys_device_batched(
+            self._h, _ptr(G_row), _ptr(G_col), _ptr(G_val), nnzG, _ptr(C_row), _ptr(C_col), _ptr(C_val), nnzC,
+            _ptr(g), _ptr(c), float(exit_tol), int(max_iters), float(rho), _ptr(lam), _ptr(dz), _ptr(iters),
+            self._stream()))
+
+    def upload_batch(self, systems):
+        """list of KKTSystem with identical sparsity -> device tensors in linsys_batched() argument order."""
+        s0 = systems[0]
+        for s in systems:
+            assert np.array_equal(s.G_row, s0.G_row) and np.array_equal(s.G_col, s0.G_col)
+            assert np.array_equal(s.C_row, s0.C_row) and np.array_equal(s.C_col, s0.C_col)
+        dev = f"cuda:{self.device}"
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+        cat = lambda name: np.concatenate([getattr(s, name) for s in systems])
+        return (t(s0.G_row, np.int32), t(s0.G_col, np.int32), t(cat("G_val"), self.np_dtype),
+                t(s0.C_row, np.int32), t(s0.C_col, np.int32), t(cat("C_val"), self.np_dtype),
+                t(cat("g"), self.np_dtype), t(cat("c"), self.np_dtype))
 
     def buffer_ptr(self, which: int) -> int:
         return int(_lib.lib().gato_solver_buffer(self._h, which))

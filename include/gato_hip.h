@@ -59,6 +59,12 @@ int gato_infer_shape(const int *C_row, int len_C_row, int len_g, int len_c, int 
 /* ---- solver object: owns the device workspace the reference allocates per call
  * (gpu_library.cu:36-45, gato_pcg.cuh:486-492) -------------------------------------------- */
 int gato_solver_create(int S, int C, int K, int dtype, int device, gato_solver **out);
+/* Batch of B independent systems of one shape and one sparsity pattern (new - the
+ * reference solves one system per call, its `testiters` loop re-solves the same one, gpu_library.cu:169).
+ * Every per-system device array of the stage-level calls is then B arrays back to back; the CSR structure
+ * (indptr/indices) is shared, G_val / C_val hold nnz entries per system.  All stages run the whole batch
+ * in one launch each (grid.y = system); the PCG runs one workgroup per system when a system fits one CU. */
+int gato_solver_create_batched(int S, int C, int K, int B, int dtype, int device, gato_solver **out);
 int gato_solver_destroy(gato_solver *s);
 /* Workspace device pointers (valid for the solver's lifetime), for stage-level tests:
  * which: 0 G_dense, 1 C_dense, 2 Ginv_dense, 3 S, 4 Pinv, 5 gamma, 6 lambda, 7 dz, 8 iters(int) */
@@ -107,6 +113,13 @@ int gato_linsys_device(gato_solver *s, const int *d_G_row, const int *d_G_col, c
                        const int *d_C_row, const int *d_C_col, const void *d_C_val,
                        const void *d_g, const void *d_c, double exit_tol, int max_iters, double rho,
                        void *d_lambda, void *d_dz, void *stream);
+
+/* Batched gato_linsys_device (solver from gato_solver_create_batched): d_G_val[B][nnz_G], d_C_val[B][nnz_C],
+ * d_g[B][N], d_c[B][S*K] -> d_lambda[B][S*K], d_dz[B][N], d_iters[B]. */
+int gato_linsys_device_batched(gato_solver *s, const int *d_G_row, const int *d_G_col, const void *d_G_val, int nnz_G,
+                               const int *d_C_row, const int *d_C_col, const void *d_C_val, int nnz_C,
+                               const void *d_g, const void *d_c, double exit_tol, int max_iters, double rho,
+                               void *d_lambda, void *d_dz, int *d_iters, void *stream);
 
 /* ---- L4  main_call (gpu_library.cu:85-234) on HOST pointers: H2D of the CSR, `testiters`
  * timed repeats of the whole solve, D2H of lambda and dz.  ms_out[testiters] (may be NULL)

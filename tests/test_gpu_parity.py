@@ -326,3 +326,29 @@ def test_true_warm_start(S, C, K, dt, opts):
     lam2, it = sol.pcg(dS, dP, dg, tol * 1e4, 300, lam=lam)
     assert int(host(it)[0]) <= 1 and rel(host(lam2), lam_w) < (1e-5 if f64 else 5e-3)   # one more step is taken before the test
     sol.close()
+
+
+@pytest.mark.parametrize("S,C,K,B,dt", [(14, 7, 50, 5, np.float64), (14, 7, 50, 7, np.float32), (2, 1, 5, 33, np.float64),
+                                        (14, 7, 120, 3, np.float64), (32, 16, 6, 4, np.float32), (14, 7, 50, 300, np.float32)])
+def test_batched_solves(S, C, K, B, dt):
+    """B independent systems (shared sparsity, own values) in one call - every stage one
+    launch for the whole batch, the PCG one workgroup per system.  Each system must equal its own oracle solve."""
+    from gato_python_amd.solver import Solver
+    systems = [synth.make_system(S, C, K, seed=100 + b) for b in range(B)]
+    sol = Solver(S, C, K, dt, batch=B)
+    dev = sol.upload_batch(systems)
+    f64 = dt == np.float64
+    tol, mi = (1e-10, 300) if f64 else (1e-5, 100)
+    lam, dz = sol.new(B * S * K), sol.new(B * sol.N)
+    iters = sol.new(B, torch.int32)
+    sol.linsys_batched(*dev, tol, mi, systems[0].rho, lam, dz, iters)
+    torch.cuda.synchronize()
+    sol.check_status()
+    lam_h, dz_h, it_h = host(lam).reshape(B, -1), host(dz).reshape(B, -1), host(iters)
+    for b in (range(B) if B <= 40 else list(range(0, B, 37)) + [B - 1]):
+        s = systems[b]
+        lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
+        assert abs(int(it_h[b]) - it_o) <= (0 if f64 else 2), (b, int(it_h[b]), it_o)
+        assert rel(lam_h[b], lam_o) < (1e-8 if f64 else 5e-3) and rel(dz_h[b], dz_o) < (1e-8 if f64 else 5e-3)
+    assert sol.get_option("batch") == B
+    sol.close()
