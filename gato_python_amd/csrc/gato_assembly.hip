@@ -6,10 +6,18 @@
 // (:758-879) and the block helpers they call (src/gato_utils.cuh: invertMatrix :468-586,
 // mat_mat_prod :609-659, mat_vec_prod :595-606, gato_ATx :664-679, store/load_block_bd :44-119).
 //
-// Design: one wavefront (64 lanes) per knot, operands staged in LDS, every Q_k / R_k inverted exactly
-// once into a separate inverse buffer (the reference inverts each Q_k twice and overwrites G_dense in
-// place while neighbouring blocks still read it - SURVEY.md D3).  Gauss-Jordan without pivoting in the
-// reference's elimination order, so fp32 results track the CUDA path.  Boundary fixes D1, D2, D4.
+// Design: one wavefront (64 lanes) per knot (per matrix in the inversion kernel), every Q_k / R_k inverted
+// exactly once into a separate inverse buffer (the reference inverts each Q_k twice and overwrites G_dense in
+// place while neighbouring blocks still read it - SURVEY.md D3).
+//  * Gauss-Jordan without pivoting, the reference's elimination order (gato_utils.cuh:468-586), REGISTER
+//    resident: lane c holds column c of the augmented [A | I]; per pivot the pivot column is broadcast with
+//    v_readlane (the pivot lane is a compile-time constant after unrolling) and every lane updates its column
+//    with n FMAs - no LDS, no barriers (the reference pays two __syncthreads and an LDS round trip per pivot).
+//  * the S x S x S products (phi = A Q^-1, theta = phi A^T + B R^-1 B^T, the four stair products) run on the
+//    matrix cores: v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 tiles with LDS operands (S = 14 pads to one
+//    16 x 16 tile, S = 32 is 2 x 2 tiles).  f32 MFMA is a k-ordered fmaf chain, i.e. the reference's own
+//    accumulation order.  This is the only place of the hot path where a dense contraction exists.
+// Boundary fixes D1, D2, D4.
 #include "gato_common.h"
 
 namespace gato {
@@ -140,29 +148,117 @@ __device__ __forceinline__ void mTv(T *out, const T *A, const T *x, int lane)
     }
 }
 
-// ---- A2a: invert every Q_k and R_k once -------------------------------------------------------
+// ---- register-resident Gauss-Jordan -----------------------------------------------------------------
+__device__ __forceinline__ float readlane_c(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double readlane_c(double v, int l)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// lane c < n holds column c of A, lane n + c holds column c of I; on return lane n + c holds column c of A^-1.
+// Same arithmetic as invertMatrix (gato_utils.cuh:468-495): pivot row *= 1/pv, other rows -= col[r]/pv * row.
+template <typename T, int n>
+__device__ __forceinline__ void gj_inverse_reg(T (&col)[n])
+{
+#pragma unroll
+    for (int p = 0; p < n; ++p) {
+        const T pvinv = (T)1 / readlane_c(col[p], p);
+        const T prow = col[p] * pvinv;                       // this lane's element of the scaled pivot row
+#pragma unroll
+        for (int r = 0; r < n; ++r) {
+            if (r != p) {
+                const T f = readlane_c(col[r], p);           // A[r][p], wave-uniform
+                col[r] = gato::fmaT(-f, prow, col[r]);
+            }
+        }
+        col[p] = prow;
+    }
+}
+
+// Inverts the n x n column-major matrix at src (LDS or global) into dst (column-major), one wave, n <= 32.
+template <typename T, int n>
+__device__ __forceinline__ void invert_to(const T *src, T *dst, int lane, T scale)
+{
+    static_assert(2 * n <= WAVE, "augmented matrix must fit one wavefront");
+    T col[n];
+#pragma unroll
+    for (int r = 0; r < n; ++r) col[r] = lane < n ? src[lane * n + r] : (T)(lane - n == r);
+    gj_inverse_reg<T, n>(col);
+    if (lane >= n && lane < 2 * n) {
+#pragma unroll
+        for (int r = 0; r < n; ++r) dst[(lane - n) * n + r] = scale * col[r];
+    }
+}
+
+// ---- small GEMMs on the matrix cores --------------------------------------------------------------------
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    __device__ static __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int lane, int j) { return 4 * (lane >> 4) + j; }       // C/D: row = 4*(lane/16)+reg
+};
+template <> struct Mfma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    __device__ static __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int lane, int j) { return (lane >> 4) + 4 * j; }       // f64: row = lane/16 + 4*reg
+};
+
+// acc tile (mt, nt) += A(M x KD, col-major, ld M) * B   where B is KD x N col-major (ld KD), or, if TB, given as
+// N x KD col-major (ld N) and used transposed.  Operands in LDS; lanes outside the matrix feed zeros.
+template <typename T, int M, int KD, int N, bool TB>
+__device__ __forceinline__ typename Mfma<T>::acc_t mfma_tile(const T *A, const T *B, int mt, int nt, int lane,
+                                                             typename Mfma<T>::acc_t acc)
+{
+    const int i = mt * 16 + (lane & 15), jn = nt * 16 + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < (KD + 3) / 4; ++ks) {
+        const int kk = ks * 4 + (lane >> 4);
+        const T a = (i < M && kk < KD) ? A[kk * M + i] : (T)0;
+        const T b = (jn < N && kk < KD) ? (TB ? B[kk * N + jn] : B[jn * KD + kk]) : (T)0;
+        acc = Mfma<T>::mma(a, b, acc);
+    }
+    return acc;
+}
+
+// out(M x N, col-major) = sign * (A B [+ A2 B2^T ...]) : generic driver taking a per-element epilogue
+template <typename T, int M, int N, typename TileFn, typename StoreFn>
+__device__ __forceinline__ void mfma_for_tiles(int lane, TileFn tile, StoreFn store)
+{
+#pragma unroll
+    for (int mt = 0; mt < (M + 15) / 16; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < (N + 15) / 16; ++nt) {
+            typename Mfma<T>::acc_t acc = {0, 0, 0, 0};
+            acc = tile(mt, nt, acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = mt * 16 + Mfma<T>::row(lane, j), c = nt * 16 + (lane & 15);
+                if (r < M && c < N) store(r, c, acc[j]);
+            }
+        }
+    }
+}
+
+// ---- A2a: invert every Q_k and R_k once: one wavefront per matrix, register resident ----------------------
 template <typename T, int S, int C>
-__global__ __launch_bounds__(WAVE) void invert_G_kernel(const T *__restrict__ Gd, T *__restrict__ Ginv, int K,
-                                                        BatchStride bs)
+__global__ __launch_bounds__(256) void invert_G_kernel(const T *__restrict__ Gd, T *__restrict__ Ginv, int K,
+                                                       BatchStride bs)
 {
     constexpr int SS = S * S, CC = C * C;
     Gd += blockIdx.y * bs.g; Ginv += blockIdx.y * bs.g;
-    __shared__ T A[SS], Ai[SS], tmp[3 * S];
-    const int lane = threadIdx.x;
-    for (int k = blockIdx.x; k < K; k += gridDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int nmat = 2 * K - 1;                                   // Q_0, R_0, Q_1, ..., Q_{K-1}
+    for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < nmat; m += gridDim.x * 4) {
+        const int k = m >> 1;
         const size_t off = (size_t)k * (SS + CC);
-        wave_sync();
-        copy_in(A, Gd + off, SS, lane);
-        wave_sync();
-        gj_inverse<T, S>(A, Ai, tmp, lane);
-        for (int i = lane; i < SS; i += WAVE) Ginv[off + i] = Ai[i];
-        if (k < K - 1) {
-            wave_sync();
-            copy_in(A, Gd + off + SS, CC, lane);
-            wave_sync();
-            gj_inverse<T, C>(A, Ai, tmp, lane);
-            for (int i = lane; i < CC; i += WAVE) Ginv[off + SS + i] = Ai[i];
-        }
+        if ((m & 1) == 0) invert_to<T, S>(Gd + off, Ginv + off, lane, (T)1);
+        else invert_to<T, C>(Gd + off + SS, Ginv + off + SS, lane, (T)1);
     }
 }
 
@@ -176,8 +272,8 @@ __global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, c
     constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C;
     Gd += blockIdx.y * bs.g; Ginv += blockIdx.y * bs.g; Cd += blockIdx.y * bs.c; g += blockIdx.y * bs.n;
     c += blockIdx.y * bs.sk; Sbd += blockIdx.y * bs.bd; Pbd += blockIdx.y * bs.bd; gamma += blockIdx.y * bs.sk;
-    __shared__ T sA[SS], sB[SC], sQim[SS], sQik[SS], sRim[CC], sPhi[SS], sBR[SC], sTh[SS], sTmp[SS];
-    __shared__ T sq[2 * S + C], sv[3 * S], stmp[3 * S];
+    __shared__ T sA[SS], sB[SC], sQim[SS], sQik[SS], sRim[CC], sPhi[SS], sBR[SC], sTh[SS];
+    __shared__ T sq[2 * S + C], sv[3 * S];
     const int lane = threadIdx.x;
     for (int k = blockIdx.x; k < K; k += gridDim.x) {
         T *Sk = Sbd + (size_t)k * 3 * SS;
@@ -210,14 +306,32 @@ __global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, c
         copy_in(sq, g + (size_t)(k - 1) * n, n, lane);                       // q_{k-1}, r_{k-1}
         copy_in(sq + n, g + (size_t)k * n, S, lane);                         // q_k
         wave_sync();
-        mm<T, S, S, S, false>(sPhi, sA, sQim, lane);                         // phi = A Q_{k-1}^-1   :277-285
-        mm<T, S, C, C, false>(sBR, sB, sRim, lane);                          // BR = B R_{k-1}^-1    :293-301
+        // phi = A Q_{k-1}^-1 (:277-285), BR = B R_{k-1}^-1 (:293-301): matrix cores, results to LDS and S[k].left
+        mfma_for_tiles<T, S, S>(lane,
+            [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sA, sQim, mt, nt, lane, acc); },
+            [&](int r, int cc, T v) {
+                sPhi[cc * S + r] = v;
+                Sk[cc * S + r] = -v;                                         // S[k].left = -phi      :388-394
+                Sk[2 * SS - 3 * SS + r * S + cc] = -v;                       // S[k-1].right = -phi^T :443-455
+            });
+        mfma_for_tiles<T, S, C>(lane,
+            [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, C, C, false>(sB, sRim, mt, nt, lane, acc); },
+            [&](int r, int cc, T v) { sBR[cc * S + r] = v; });
         mv<T, S, S>(sv, sQik, sq + n, lane);                                 // Q_k^-1 q_k           :306-310
         wave_sync();
         mv<T, S, S>(sv + S, sPhi, sq, lane);                                 // phi q_{k-1}          :316-320
         mv<T, S, C>(sv + 2 * S, sBR, sq + S, lane);                          // BR r_{k-1}           :324-328
-        mm<T, S, S, S, true>(sTh, sPhi, sA, lane);                           // phi A^T              :342-351
-        mm<T, S, C, S, true>(sTmp, sBR, sB, lane);                           // BR B^T               :368-377
+        // theta = phi A^T + Q_k^-1 + BR B^T (:342-384): both products accumulate in the same MFMA tile
+        mfma_for_tiles<T, S, S>(lane,
+            [&](int mt, int nt, typename Mfma<T>::acc_t acc) {
+                acc = mfma_tile<T, S, S, S, true>(sPhi, sA, mt, nt, lane, acc);
+                return mfma_tile<T, S, C, S, true>(sBR, sB, mt, nt, lane, acc);
+            },
+            [&](int r, int cc, T v) {
+                const T th = v + sQik[cc * S + r];
+                sTh[cc * S + r] = th;
+                Sk[SS + cc * S + r] = -th;                                   // S[k].main   :398-404
+            });
         wave_sync();
         for (int i = lane; i < S; i += WAVE) {
             T gt = sv[i] - c[(size_t)k * S + i];                             // :311-313
@@ -225,20 +339,11 @@ __global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, c
             gamma[(size_t)k * S + i] = -gt;                                  // :435-438
         }
         for (int i = lane; i < SS; i += WAVE) {
-            T th = sTh[i] + sQik[i];                                         // :362-364
-            th += sTmp[i];                                                   // :382-384
-            sTh[i] = th;
-            Sk[i] = -sPhi[i];                                                // S[k].left   :388-394
-            Sk[SS + i] = -th;                                                // S[k].main   :398-404
-            const int r = i % S, cc = i / S;
-            Sk[2 * SS + i - 3 * SS] = -sPhi[cc + r * S];                     // S[k-1].right = -phi^T  :443-455
             Pk[i] = (T)0;                                                    // stair blocks come from form_ss
             Pk[2 * SS + i] = (T)0;
             if (k == K - 1) Sk[2 * SS + i] = (T)0;                           // last right: unused (:166-174)
         }
-        wave_sync();
-        gj_inverse<T, S>(sTh, sTmp, stmp, lane);                             // theta^-1    :407-414
-        for (int i = lane; i < SS; i += WAVE) Pk[SS + i] = -sTmp[i];         // Pinv[k].main :415-422
+        invert_to<T, S>(sTh, Pk + SS, lane, (T)-1);                          // Pinv[k].main = -theta^-1  :407-422
     }
 }
 
@@ -248,7 +353,7 @@ __global__ __launch_bounds__(WAVE) void ss_kernel(const T *__restrict__ Sbd, T *
 {
     constexpr int SS = S * S;
     Sbd += blockIdx.y * bs.bd; Pbd += blockIdx.y * bs.bd;
-    __shared__ T sPm[SS], sX[SS], sPn[SS], sT[SS], sO[SS];
+    __shared__ T sPm[SS], sX[SS], sPn[SS], sT[SS];
     const int lane = threadIdx.x;
     for (int k = blockIdx.x; k < K; k += gridDim.x) {
         T *Pk = Pbd + (size_t)k * 3 * SS;
@@ -258,23 +363,26 @@ __global__ __launch_bounds__(WAVE) void ss_kernel(const T *__restrict__ Sbd, T *
             copy_in(sX, Sbd + (size_t)k * 3 * SS, SS, lane);                 // S[k].left
             copy_in(sPn, Pbd + (size_t)(k - 1) * 3 * SS + SS, SS, lane);     // Pinv[k-1].main
             wave_sync();
-            mm<T, S, S, S, false>(sT, sPm, sX, lane);
+            mfma_for_tiles<T, S, S>(lane,
+                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sPm, sX, mt, nt, lane, acc); },
+                [&](int r, int cc, T v) { sT[cc * S + r] = v; });
             wave_sync();
-            mm<T, S, S, S, false>(sO, sT, sPn, lane);
-            wave_sync();
-            for (int i = lane; i < SS; i += WAVE) Pk[i] = -sO[i];
+            mfma_for_tiles<T, S, S>(lane,
+                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sT, sPn, mt, nt, lane, acc); },
+                [&](int r, int cc, T v) { Pk[cc * S + r] = -v; });
         }
         if (k < K - 1) {                                                     // :614-648 (k < K-1 only: D1)
             wave_sync();
-            const T *Sl1 = Sbd + (size_t)(k + 1) * 3 * SS;                   // S[k+1].left, read transposed
-            for (int i = lane; i < SS; i += WAVE) sX[(i % S) * S + i / S] = Sl1[i];
+            copy_in(sX, Sbd + (size_t)(k + 1) * 3 * SS, SS, lane);           // S[k+1].left, used transposed
             copy_in(sPn, Pbd + (size_t)(k + 1) * 3 * SS + SS, SS, lane);     // Pinv[k+1].main
             wave_sync();
-            mm<T, S, S, S, false>(sT, sPm, sX, lane);
+            mfma_for_tiles<T, S, S>(lane,
+                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, true>(sPm, sX, mt, nt, lane, acc); },
+                [&](int r, int cc, T v) { sT[cc * S + r] = v; });
             wave_sync();
-            mm<T, S, S, S, false>(sO, sT, sPn, lane);
-            wave_sync();
-            for (int i = lane; i < SS; i += WAVE) Pk[2 * SS + i] = -sO[i];
+            mfma_for_tiles<T, S, S>(lane,
+                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sT, sPn, mt, nt, lane, acc); },
+                [&](int r, int cc, T v) { Pk[2 * SS + cc * S + r] = -v; });
         }
     }
 }
@@ -360,7 +468,8 @@ template <typename T, int S, int C>
 int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const T *c, T *Sbd, T *Pbd,
                       T *gamma, T *Ginv, hipStream_t st)
 {
-    hipLaunchKernelGGL((invert_G_kernel<T, S, C>), dim3(knot_grid(d.K), d.B), dim3(WAVE), 0, st, Gd, Ginv, d.K,
+    const int nblk = (2 * d.K - 1 + 3) / 4;
+    hipLaunchKernelGGL((invert_G_kernel<T, S, C>), dim3(nblk < 8192 ? nblk : 8192, d.B), dim3(256), 0, st, Gd, Ginv, d.K,
                        batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL((schur_kernel<T, S, C>), dim3(knot_grid(d.K), d.B), dim3(WAVE), 0, st, Gd, Ginv, Cd, g, c, d.K,
