@@ -3,6 +3,7 @@
 // (gpu_library.cu:85-234).
 #include <cstdarg>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "gato_common.h"
@@ -106,6 +107,8 @@ struct gato_solver {
     // device copies of host CSR inputs for gato_linsys_solve_* (sized on first use)
     char *in_arena;
     size_t in_bytes;
+    char *pin;            // pinned host staging (inputs, then iters | lambda | dz)
+    size_t pin_bytes;
     int last_groups, last_threads, last_mode;
     int time_pcg, stamp_pcg, ablate, no_single_lds, true_warm_start;
     hipEvent_t ev_pcg0, ev_pcg1;
@@ -280,6 +283,7 @@ extern "C" int gato_solver_destroy(gato_solver *s)
     if (s->ev_pcg1) hipEventDestroy(s->ev_pcg1);
     if (s->arena) hipFree(s->arena);
     if (s->in_arena) hipFree(s->in_arena);
+    if (s->pin) hipHostFree(s->pin);
     delete s;
     return GATO_OK;
 }
@@ -543,30 +547,62 @@ static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const i
                   C_row[len_C_row - 1], nnz_C);
         return GATO_EINVAL;
     }
-    gato_solver *s = nullptr;
-    int rc = gato_solver_create(S, C, K, dtype, 0, &s);
-    if (rc) return rc;
+    // The reference allocates and frees 22 device buffers per call (gpu_library.cu:36-45,140-147; gato_pcg.cuh:486-492).
+    // Here the solver of the most recent (S, C, K, dtype) and its input staging area are kept for the next call.
+    static std::mutex cache_mu;
+    static gato_solver *cached = nullptr;
+    std::lock_guard<std::mutex> lock(cache_mu);
+    gato_solver *s = cached;
+    int rc;
+    if (!s || s->d.S != S || s->d.C != C || s->d.K != K || s->dtype != dtype || s->d.B != 1) {
+        if (s) gato_solver_destroy(s);
+        cached = s = nullptr;
+        if ((rc = gato_solver_create(S, C, K, dtype, 0, &s))) return rc;
+        cached = s;
+    } else {
+        hipSetDevice(s->device);
+    }
     const char *env = getenv("GATO_PCG_MODE");
-    if (env) s->pcg_mode = atoi(env);
+    s->pcg_mode = env ? atoi(env) : GATO_PCG_AUTO;
 
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += align_up(b ? b : 8); return o; };
     const size_t oGr = take(sizeof(int) * len_G_row), oGc = take(sizeof(int) * nnz_G), oGv = take(sizeof(T) * nnz_G);
     const size_t oCr = take(sizeof(int) * len_C_row), oCc = take(sizeof(int) * nnz_C), oCv = take(sizeof(T) * nnz_C);
     const size_t og = take(sizeof(T) * len_g), oc = take(sizeof(T) * len_c);
-    hipError_t e = hipMalloc((void **)&s->in_arena, off);
-    if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(e)); gato_solver_destroy(s); return GATO_EHIP; }
+    hipError_t e = hipSuccess;
+    if (s->in_bytes < off) {
+        if (s->in_arena) hipFree(s->in_arena);
+        s->in_arena = nullptr; s->in_bytes = 0;
+        e = hipMalloc((void **)&s->in_arena, off);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(e)); return GATO_EHIP; }
+        s->in_bytes = off;
+    }
     char *a = s->in_arena;
     hipStream_t st = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    auto fail = [&](int code) { if (ev0) hipEventDestroy(ev0); if (ev1) hipEventDestroy(ev1); gato_solver_destroy(s); return code; };
-#define CP(dst, src, bytes) \
-    if ((bytes) && (e = hipMemcpyAsync(a + dst, src, bytes, hipMemcpyHostToDevice, st)) != hipSuccess) { \
-        set_error("H2D copy failed: %s", hipGetErrorString(e)); return fail(GATO_EHIP); }
-    CP(oGr, G_row, sizeof(int) * len_G_row) CP(oGc, G_col, sizeof(int) * nnz_G) CP(oGv, G_val, sizeof(T) * nnz_G)
-    CP(oCr, C_row, sizeof(int) * len_C_row) CP(oCc, C_col, sizeof(int) * nnz_C) CP(oCv, C_val, sizeof(T) * nnz_C)
-    CP(og, g, sizeof(T) * len_g) CP(oc, c, sizeof(T) * len_c)
-#undef CP
+    auto fail = [&](int code) { if (ev0) hipEventDestroy(ev0); if (ev1) hipEventDestroy(ev1); return code; };
+    // one H2D transfer: the eight input arrays are packed into a pinned staging buffer laid out like the device
+    // arena (the reference issues eight blocking cudaMemcpy from pageable memory, gpu_library.cu:150-157)
+    if (s->pin_bytes < off + 64 + sizeof(T) * ((size_t)S * K + (size_t)N)) {
+        if (s->pin) hipHostFree(s->pin);
+        s->pin = nullptr; s->pin_bytes = 0;
+        const size_t want = off + 64 + sizeof(T) * ((size_t)S * K + (size_t)N) + 256;
+        if ((e = hipHostMalloc((void **)&s->pin, want, hipHostMallocDefault)) != hipSuccess) {
+            set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return fail(GATO_EHIP);
+        }
+        s->pin_bytes = want;
+    }
+    memcpy(s->pin + oGr, G_row, sizeof(int) * len_G_row); memcpy(s->pin + oGc, G_col, sizeof(int) * nnz_G);
+    memcpy(s->pin + oGv, G_val, sizeof(T) * nnz_G);       memcpy(s->pin + oCr, C_row, sizeof(int) * len_C_row);
+    memcpy(s->pin + oCc, C_col, sizeof(int) * nnz_C);     memcpy(s->pin + oCv, C_val, sizeof(T) * nnz_C);
+    memcpy(s->pin + og, g, sizeof(T) * len_g);            memcpy(s->pin + oc, c, sizeof(T) * len_c);
+    if ((e = hipMemcpyAsync(a, s->pin, off, hipMemcpyHostToDevice, st)) != hipSuccess) {
+        set_error("H2D copy failed: %s", hipGetErrorString(e));
+        return fail(GATO_EHIP);
+    }
+    char *pout = s->pin + off;                               // pinned landing area: iters | lambda | dz
     hipEventCreate(&ev0);
     hipEventCreate(&ev1);
     int iters = 0;
@@ -576,9 +612,9 @@ static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const i
                                 (const int *)(a + oCc), a + oCv, a + og, a + oc, (double)exit_tol, max_iters,
                                 (double)rho, nullptr, nullptr, st);
         if (rc) return fail(rc);
-        if ((e = hipMemcpyAsync(lambda_out, s->lambda, sizeof(T) * (size_t)S * K, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-            (e = hipMemcpyAsync(dz_out, s->dz, sizeof(T) * (size_t)N, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-            (e = hipMemcpyAsync(&iters, s->iters, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) {
+        if ((e = hipMemcpyAsync(pout + 64, s->lambda, sizeof(T) * (size_t)S * K, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+            (e = hipMemcpyAsync(pout + 64 + sizeof(T) * (size_t)S * K, s->dz, sizeof(T) * (size_t)N, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+            (e = hipMemcpyAsync(pout, s->iters, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) {
             set_error("D2H copy failed: %s", hipGetErrorString(e));
             return fail(GATO_EHIP);
         }
@@ -587,12 +623,15 @@ static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const i
             set_error("solve failed: %s", hipGetErrorString(e));
             return fail(GATO_EHIP);
         }
+        iters = *(const int *)pout;
         float ms = 0;
         hipEventElapsedTime(&ms, ev0, ev1);
         if (ms_out) ms_out[i] = ms;
         if (i == 0 && iters_out) *iters_out = iters;            // the reference prints the first run's count (:189-191)
         if ((rc = gato_pcg_status(s, nullptr))) return fail(rc);
     }
+    memcpy(lambda_out, pout + 64, sizeof(T) * (size_t)S * K);
+    memcpy(dz_out, pout + 64 + sizeof(T) * (size_t)S * K, sizeof(T) * (size_t)N);
     return fail(GATO_OK);
 }
 
