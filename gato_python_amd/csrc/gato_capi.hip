@@ -110,7 +110,7 @@ struct gato_solver {
     char *pin;            // pinned host staging (inputs, then iters | lambda | dz)
     size_t pin_bytes;
     int last_groups, last_threads, last_mode;
-    int time_pcg, stamp_pcg, ablate, no_single_lds, true_warm_start;
+    int time_pcg, stamp_pcg, ablate, no_single_lds, true_warm_start, no_pair, plan_pair;
     hipEvent_t ev_pcg0, ev_pcg1;
     // knot-sharded PCG state (gato_shard_pcg_*)
     struct {
@@ -313,6 +313,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "stamp_pcg")) s->stamp_pcg = value;
     else if (!strcmp(name, "ablate")) s->ablate = value;
     else if (!strcmp(name, "no_single_lds")) s->no_single_lds = value;
+    else if (!strcmp(name, "no_pair")) s->no_pair = value;
     else if (!strcmp(name, "true_warm_start")) s->true_warm_start = value;
     else if (!strcmp(name, "batch_nnz_G")) s->d.nnzG = value;
     else if (!strcmp(name, "batch_nnz_C")) s->d.nnzC = value;
@@ -343,6 +344,7 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "last_groups")) *value = s->last_groups;
     else if (!strcmp(name, "last_threads")) *value = s->last_threads;
     else if (!strcmp(name, "last_mode")) *value = s->last_mode;
+    else if (!strcmp(name, "last_pair")) *value = s->plan_pair;
     else if (!strcmp(name, "num_cus")) *value = s->num_cus;
     else if (!strcmp(name, "batch")) *value = s->d.B;
     else if (!strcmp(name, "max_resident_knots")) *value = s->plan.max_knots_per_wg * (s->num_cus < 256 ? s->num_cus : 256);
@@ -392,6 +394,13 @@ static int plan_resident(gato_solver *s, int *groups, int *threads, int *kpw)
         if (t < 64) t = 64;
         if (t > maxT) return 0;
     }
+    s->plan_pair = 0;
+    if (t == 0 && g <= 1 && !s->no_pair && s->plan.pair_threads > 0 && K * (S / 2) <= s->plan.pair_threads) {
+        // fp32: one workgroup, two rows per lane (packed FMAs, half the waves)
+        *groups = 1; *threads = (K * (S / 2) + 63) / 64 * 64; *kpw = K;
+        s->plan_pair = 1;
+        return 1;
+    }
     if (t == 0) {
         // auto: one workgroup while the problem fits one CU's registers (no inter-CU traffic at all);
         // otherwise 512-thread workgroups (measured best on MI355X: 2 waves per SIMD hide the LDS latency
@@ -438,6 +447,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.lambda0 = s->true_warm_start ? d_lambda : nullptr;      // in place: every lane reads its lambda0 first
         a.K = s->d.K; a.max_iters = max_iters; a.exit_tol = exit_tol;
         a.batch = batch;
+        a.pair = s->plan_pair;
         a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
         a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
         a.final_eta = s->final_eta;

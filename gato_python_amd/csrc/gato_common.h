@@ -108,6 +108,7 @@ struct PcgLaunch {
     int max_iters;
     double exit_tol;
     int batch;                   // > 1: blockIdx.x = system index, one workgroup per system (groups must be 1)
+    int pair;                    // fp32 one-workgroup kernel with two rows per lane
     int knots_per_wg;            // contiguous knots owned by each workgroup (last may own fewer)
     int groups;                  // W = gridDim.x
     int threads;                 // blockDim.x (multiple of 64, >= knots_per_wg * S)
@@ -134,6 +135,7 @@ struct PcgPlan {
     int max_threads;     // launch bound of the instantiation
     int max_knots_per_wg;
     int single_max_threads;   // > max_threads: a one-workgroup variant (Pinv rows partly in LDS) exists up to this size
+    int pair_threads;         // > 0: fp32 one-workgroup kernel with two rows per lane, up to this many threads
 };
 
 // Per-(dtype, S, C) kernel launchers, defined in the .hip files and instantiated for GATO_SHAPES.

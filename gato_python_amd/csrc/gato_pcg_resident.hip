@@ -439,6 +439,123 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     }
 }
 
+// ---- fp32, one workgroup (or one workgroup per system of a batch), TWO rows per lane --------------------------
+// The single-workgroup loop is instruction-issue bound: with two rows of the same knot per lane
+// the operand-window reads are shared by both rows, the FMAs pair up as v_pk_fma_f32 and the wave count halves
+// (IIWA 14/7/50: 6 waves instead of 11), and the one-CU regime extends to K*S <= 2*MAXT rows.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int S, int MAXT>
+__global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
+{
+    constexpr int H = S / 2;                       // lanes per knot
+    constexpr int SP = pad_to(S, 4);
+    constexpr int MAXK = (MAXT + H - 1) / H;
+    static_assert(S % 2 == 0, "two rows per lane need an even STATE_SIZE");
+    __shared__ __attribute__((aligned(16))) float xs[2][(MAXK + 2) * SP];
+    __shared__ float wpart[2][(MAXT + 63) / 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int K = a.K;
+    const size_t sys = a.batch > 1 ? blockIdx.x : 0;
+    const int j = tid / H, h = tid - j * H;        // knot, row pair (h, h + H)
+    const bool active = j < K;
+    const int r0 = h, r1 = h + H;
+
+    const float *__restrict__ dS = static_cast<const float *>(a.S_bd) + sys * 3 * S * S * K;
+    const float *__restrict__ dP = static_cast<const float *>(a.P_bd) + sys * 3 * S * S * K;
+    const float *__restrict__ dG = static_cast<const float *>(a.gamma) + sys * S * K;
+    float *__restrict__ dL = static_cast<float *>(a.lambda) + sys * S * K;
+
+    f32x2 sm[3 * S], pm[3 * S];
+    {
+        const size_t base = (size_t)(active ? j : 0) * 3 * S * S;
+#pragma unroll
+        for (int c = 0; c < 3 * S; ++c) {
+            const bool ok = active && !(j == 0 && c < S) && !(j == K - 1 && c >= 2 * S);   // gato_utils.cuh:157-174
+            sm[c] = ok ? f32x2{dS[base + c * S + r0], dS[base + c * S + r1]} : f32x2{0.f, 0.f};
+            pm[c] = ok ? f32x2{dP[base + c * S + r0], dP[base + c * S + r1]} : f32x2{0.f, 0.f};
+        }
+    }
+    for (int i = tid; i < 2 * (MAXK + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = 0.f;
+    if (tid == 0 && sys == 0) *a.status = 0;
+    __syncthreads();
+
+    auto times_window = [&](const f32x2 (&m)[3 * S], const float *xw) -> f32x2 {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+#pragma unroll
+            for (int i = 0; i < SP / 4; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xw + b * SP + i * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i * 4 + e < S) acc = __builtin_elementwise_fma(m[b * S + i * 4 + e], f32x2{v[e], v[e]}, acc);
+            }
+        }
+        return acc;
+    };
+    unsigned epoch = 0;
+    auto block_sum = [&](float prod) -> float {
+        ++epoch;
+        const float ws = wave_sum(prod);
+        float *wp = wpart[epoch & 1];
+        if (lane == 0) wp[wave] = ws;
+        __syncthreads();
+        return wave_sum(lane < nwaves ? wp[lane] : 0.f);
+    };
+    auto put = [&](float *buf, f32x2 v) {
+        if (active) { buf[(j + 1) * SP + r0] = v[0]; buf[(j + 1) * SP + r1] = v[1]; }
+    };
+
+    f32x2 lam = {0.f, 0.f};
+    f32x2 r = active ? f32x2{dG[(size_t)j * S + r0], dG[(size_t)j * S + r1]} : f32x2{0.f, 0.f};
+    if (a.lambda0) {                                                       // true warm start (opt-in)
+        const float *__restrict__ dL0 = static_cast<const float *>(a.lambda0) + sys * S * K;
+        if (active) lam = f32x2{dL0[(size_t)j * S + r0], dL0[(size_t)j * S + r1]};
+        put(xs[0], lam);
+        __syncthreads();
+        r -= times_window(sm, &xs[0][j * SP]);
+        __syncthreads();
+    }
+    put(xs[1], r);
+    __syncthreads();
+    f32x2 rt = times_window(pm, &xs[1][j * SP]);                          // gato_pcg.cuh:316-335
+    float eta = block_sum(r[0] * rt[0] + r[1] * rt[1]), eta_new = 0.f;
+    f32x2 p = rt, ups;
+    put(xs[0], p);
+    __syncthreads();
+    int iters = a.max_iters;
+    const float tol = (float)a.exit_tol;
+    for (int it = 0; it < a.max_iters; ++it) {                             // gato_pcg.cuh:348
+        ups = times_window(sm, &xs[0][j * SP]);
+        const float v = block_sum(p[0] * ups[0] + p[1] * ups[1]);
+        const float alpha = eta / v;
+        lam += alpha * p;
+        r -= alpha * ups;
+        put(xs[1], r);
+        __syncthreads();
+        rt = times_window(pm, &xs[1][j * SP]);
+        eta_new = block_sum(r[0] * rt[0] + r[1] * rt[1]);
+        if (fabsf(eta_new) < tol) { iters = it; break; }                   // :404-411
+        const float beta = eta_new / eta;
+        p = rt + beta * p;
+        put(xs[0], p);
+        eta = eta_new;
+        __syncthreads();
+    }
+    if (active) { dL[(size_t)j * S + r0] = lam[0]; dL[(size_t)j * S + r1] = lam[1]; }
+    if (tid == 0) {
+        a.iters[sys] = iters;
+        if (a.final_eta && sys == 0) *a.final_eta = (double)eta_new;
+    }
+}
+
+// threads of the two-rows-per-lane kernel: 2*3S*2 matrix registers + window + state must stay under the cap
+template <int S> struct PairThreads { static constexpr int v = (12 * S + 3 * S + 48) <= 256 ? 512 : ((12 * S + 3 * S + 48) <= 512 ? 256 : 0); };
+template <> struct PairThreads<14> { static constexpr int v = 512; };     // measured: 248 VGPRs, no spill at the 256 cap
+
 // Generic rule for shapes added at build time: VGPRs per lane ~ matrix rows (6S words, x2 for fp64) + the
 // operand window the compiler keeps in flight (3S words) + ~40; the specialisations below are the measured ones.
 template <typename T, int S> struct MaxThreads {
@@ -468,12 +585,27 @@ int pcg_resident_plan(PcgPlan *plan)
     plan->max_threads = MaxThreads<T, S>::v;
     plan->max_knots_per_wg = MaxThreads<T, S>::v / S;
     plan->single_max_threads = SingleCu<T, S>::threads;
+    plan->pair_threads = (sizeof(T) == 4 && S % 2 == 0) ? PairThreads<S>::v : 0;
     return GATO_OK;
 }
 
 template <typename T, int S>
 int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
 {
+    if constexpr (sizeof(T) == 4 && S % 2 == 0 && PairThreads<S>::v > 0) {
+        if (a.pair) {
+            constexpr int PT = PairThreads<S>::v;
+            if (a.groups != 1 || a.threads > PT || a.threads % 64 != 0 || a.K * (S / 2) > a.threads) {
+                set_error("pcg_resident(pair): bad geometry K=%d threads=%d max=%d", a.K, a.threads, PT);
+                return GATO_EINVAL;
+            }
+            if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
+            hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT>), dim3(a.batch > 1 ? a.batch : 1), dim3(a.threads), 0, st, a);
+            GATO_HIP_CHECK(hipGetLastError());
+            if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
+            return GATO_OK;
+        }
+    }
     constexpr int MAXT0 = MaxThreads<T, S>::v;
     constexpr int SINGLE_T = SingleCu<T, S>::threads;
     const bool single_lds = SINGLE_T > MAXT0 && a.groups == 1 && a.threads > MAXT0 && a.threads <= SINGLE_T;

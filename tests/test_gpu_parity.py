@@ -136,7 +136,10 @@ def test_golden_fp64_whole_solve(golden_dir, name, S, C, K, seed, dq, tol, mi):
 
 
 @pytest.mark.parametrize("S,C,K,dt,opts", [
-    (14, 7, 50, np.float32, {}),                                  # one workgroup
+    (14, 7, 50, np.float32, {}),                                  # one workgroup, two rows per lane (packed FMA)
+    (14, 7, 50, np.float32, dict(no_pair=1)),                     # one workgroup, one row per lane
+    (14, 7, 73, np.float32, {}),                                  # largest two-rows-per-lane system
+    (2, 1, 400, np.float32, {}),
     (14, 7, 50, np.float64, {}),                                  # one workgroup, Pinv row tails in LDS
     (14, 7, 50, np.float64, dict(no_single_lds=1)),               # two workgroups (register budget)
     (14, 7, 37, np.float64, {}),                                  # LDS-tail variant with idle lanes
