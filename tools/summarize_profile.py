@@ -53,7 +53,7 @@ def counter(kind):
 
 fetch, write = counter("fetch"), counter("write")
 # bench workloads -> (kernel template prefix, S, dtype) ; grid identifies K
-WL = {"iiwa_14_7_k50_f64": ("pcg_resident_kernel<double, 14", 50), "iiwa_14_7_k50_f32": ("pcg_resident_kernel<float, 14", 50),
+WL = {"iiwa_14_7_k50_f64": ("pcg_resident_kernel<double, 14", 50), "iiwa_14_7_k50_f32": ("pcg_single_f32x2_kernel<14", 50),
       "iiwa_14_7_k512_f32": ("pcg_resident_kernel<float, 14", 512), "iiwa_14_7_k4096_f32": ("pcg_resident_kernel<float, 14", 4096),
       "iiwa_14_7_k4096_f64": ("pcg_resident_kernel<double, 14", 4096), "s32_c16_k1024_f32": ("pcg_resident_kernel<float, 32", 1024)}
 bench = one(f"prof_{tag}_bench.json")
@@ -63,7 +63,8 @@ if bench:
         d = json.loads(open(bench).read().strip().splitlines()[-1])
         geom[d["config"]["workload"]] = d["config"]["pcg_workgroups"] * d["config"]["pcg_threads"]
         for r in d.get("sweep", []):
-            geom[r["workload"]] = r["pcg_groups"] * r["pcg_threads"]
+            if "pcg_groups" in r and r.get("pcg_groups"):
+                geom[r["workload"]] = r["pcg_groups"] * r["pcg_threads"]
     except Exception as e:
         print("bench json unreadable:", e)
 traffic = {}
@@ -97,4 +98,19 @@ if n_step:
         note="per gato_pcg call of 20 iterations = 41 stream_step launches; (2 x FETCH_SIZE + WRITE_SIZE) averaged per "
              "launch x 41; 16-B-per-lane LDS-DMA stream: the x2 FETCH_SIZE correction applies")
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+
+# matrix-core counters of the assembly kernels
+mf = one(f"prof_{tag}_mfma/*/*_counter_collection.csv")
+if mf:
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(mf)):
+        n = short(r["Kernel_Name"])
+        if any(x in n for x in ("schur_kernel", "ss_kernel", "invert_G_kernel", "pcg_resident", "pcg_single", "stream_step")):
+            acc[(n, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    names = ["SQ_INSTS_VALU_MFMA_F32", "SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"]
+    with open(os.path.join(out, f"{tag}_mfma_counters.csv"), "w") as f:
+        f.write("kernel,grid_threads,launches," + ",".join(n + "_avg" for n in names) + "\n")
+        for k, v in sorted(acc.items()):
+            row = [f"{sum(v[n]) / len(v[n]):.0f}" if v.get(n) else "" for n in names]
+            f.write(f'"{k[0]}",{k[1]},{len(next(iter(v.values())))},' + ",".join(row) + "\n")
 print("wrote", sorted(os.listdir(out)))
