@@ -355,3 +355,36 @@ def test_batched_solves(S, C, K, B, dt):
         assert rel(lam_h[b], lam_o) < (1e-8 if f64 else 5e-3) and rel(dz_h[b], dz_o) < (1e-8 if f64 else 5e-3)
     assert sol.get_option("batch") == B
     sol.close()
+
+
+def test_random_resident_geometries():
+    """Randomised launch geometries of the resident kernel (ragged knot splits, 1-knot workgroups, every thread
+    count) against the oracle in fp64: same iteration count, lambda to 1e-9."""
+    rng = np.random.default_rng(2024)
+    S, C = 14, 7
+    cache = {}
+    for trial in range(36):
+        K = int(rng.choice([3, 17, 50, 51, 97, 200, 333]))
+        if K not in cache:
+            s = synth.make_system(S, C, K, seed=K)
+            Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, np.float64)
+            Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+            Pb = co.form_ss(Sb, Pb, S, K)
+            cache[K] = (Sb, Pb, gam) + co.pcg(Sb, Pb, gam, S, K, 1e-9, 300)
+        Sb, Pb, gam, lam_o, it_o = cache[K]
+        threads = int(rng.choice([64, 128, 192, 256, 320, 448, 512]))
+        groups = int(rng.integers(0, min(K, 40) + 1))
+        sol = make_solver(S, C, K, np.float64)
+        sol.set_option("pcg_mode", _lib.PCG_RESIDENT)
+        sol.set_option("no_single_lds", int(rng.integers(0, 2)))
+        sol.set_option("pcg_threads", threads if groups == 0 else 0)
+        sol.set_option("pcg_groups", groups)
+        try:
+            lam, it = sol.pcg(sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam), 1e-9, 300)
+        except _lib.GatoError as e:
+            assert e.code == -1, e          # geometry that does not fit is refused, never mis-run
+            sol.close()
+            continue
+        assert int(host(it)[0]) == it_o, (K, threads, groups, int(host(it)[0]), it_o)
+        assert rel(host(lam), lam_o) < 1e-8, (K, threads, groups)   # summation order differs with the split
+        sol.close()
