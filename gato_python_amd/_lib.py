@@ -27,6 +27,7 @@ SYMBOLS = [
     "gato_form_ss", "gato_pcg", "gato_pcg_status", "gato_pcg_last_ms", "gato_compute_dz", "gato_linsys_device",
     "gato_linsys_solve_f32", "gato_linsys_solve_f64",
     "gato_shard_pcg_init", "gato_shard_pcg_phase_a", "gato_shard_pcg_phase_b", "gato_shard_pcg_finish",
+    "gato_shard_pcg_done", "gato_linsys_device_blocks",
 ]
 
 
@@ -76,6 +77,8 @@ def lib() -> ct.CDLL:
         L.gato_shard_pcg_phase_a.argtypes = [vp, i, vp, vp, vp, vp]
         L.gato_shard_pcg_phase_b.argtypes = [vp, i, vp, vp, vp, vp]
         L.gato_shard_pcg_finish.argtypes = [vp, vp, vp, vp, vp]
+        L.gato_shard_pcg_done.argtypes = [vp, ct.POINTER(ct.c_int), vp]
+        L.gato_linsys_device_blocks.argtypes = [vp, vp, vp, vp, vp, d, i, d, vp, vp, vp]
         f = ct.c_float
         L.gato_linsys_solve_f32.argtypes = [ip, i, ip, vp, i, ip, i, ip, vp, i, vp, i, vp, i, vp,
                                             i, i, i, i, f, i, i, f, vp, vp, vp, vp]

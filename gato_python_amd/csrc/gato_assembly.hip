@@ -71,6 +71,20 @@ __global__ void convert_kernel(const int *__restrict__ G_row, const int *__restr
     }
 }
 
+// ---- N4: blocks handed over directly: copy G_dense adding rho on the diagonals of Q_k and R_k (what
+// csr_to_custom_G does to structurally present diagonal entries, gato_schur.cuh:697,:700)
+template <typename T, int S, int C>
+__global__ void add_rho_kernel(const T *__restrict__ G_in, T rho, T *__restrict__ Gd, size_t n_per_sys, int B)
+{
+    constexpr int SS = S * S, CC = C * C;
+    const size_t total = n_per_sys * B;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t w = (i % n_per_sys) % (SS + CC);
+        const bool diag = w < SS ? (w % (S + 1) == 0) : ((w - SS) % (C + 1) == 0);
+        Gd[i] = G_in[i] + (diag ? rho : (T)0);
+    }
+}
+
 // ---- block helpers on LDS operands, executed by one wavefront ---------------------------------
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }   // blockDim == 64: one wave
 
@@ -462,6 +476,16 @@ int launch_convert(const Dims &d, const int *G_row, const int *G_col, const T *G
     return GATO_OK;
 }
 
+template <typename T, int S, int C>
+int launch_add_rho(const Dims &d, const T *G_in, T rho, T *Gd, hipStream_t st)
+{
+    const size_t total = d.g_dense() * d.B;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL((add_rho_kernel<T, S, C>), dim3(blocks), dim3(256), 0, st, G_in, rho, Gd, d.g_dense(), d.B);
+    GATO_HIP_CHECK(hipGetLastError());
+    return GATO_OK;
+}
+
 static inline int knot_grid(int K) { return K < 8192 ? K : 8192; }
 
 template <typename T, int S, int C>
@@ -502,6 +526,8 @@ int launch_compute_dz(const Dims &d, const T *Ginv, const T *Cd, const T *g, con
     template int launch_convert<double, S_, C_>(const Dims &, const int *, const int *, const double *,           \
                                                 const int *, const int *, const double *, double, double *,      \
                                                 double *, hipStream_t);                                          \
+    template int launch_add_rho<float, S_, C_>(const Dims &, const float *, float, float *, hipStream_t);             \
+    template int launch_add_rho<double, S_, C_>(const Dims &, const double *, double, double *, hipStream_t);          \
     template int launch_form_schur<float, S_, C_>(const Dims &, const float *, const float *, const float *,     \
                                                   const float *, float *, float *, float *, float *, hipStream_t); \
     template int launch_form_schur<double, S_, C_>(const Dims &, const double *, const double *, const double *, \

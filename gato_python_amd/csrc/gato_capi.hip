@@ -30,6 +30,9 @@ static Ops make_ops(int dtype)
                    const void *cv, double rho, void *Gd, void *Cd, hipStream_t st) {
         return launch_convert<T, S, C>(d, gr, gc, (const T *)gv, cr, cc, (const T *)cv, (T)rho, (T *)Gd, (T *)Cd, st);
     };
+    o.add_rho = [](const Dims &d, const void *Gin, double rho, void *Gd, hipStream_t st) {
+        return launch_add_rho<T, S, C>(d, (const T *)Gin, (T)rho, (T *)Gd, st);
+    };
     o.form_schur = [](const Dims &d, const void *Gd, const void *Cd, const void *g, const void *c, void *Sb,
                       void *Pb, void *gam, void *Gi, hipStream_t st) {
         return launch_form_schur<T, S, C>(d, (const T *)Gd, (const T *)Cd, (const T *)g, (const T *)c, (T *)Sb,
@@ -521,6 +524,27 @@ extern "C" int gato_linsys_device(gato_solver *s, const int *d_G_row, const int 
     return GATO_OK;
 }
 
+extern "C" int gato_linsys_device_blocks(gato_solver *s, const void *d_G_blocks, const void *d_C_blocks, const void *d_g,
+                                         const void *d_c, double exit_tol, int max_iters, double rho, void *d_lambda,
+                                         void *d_dz, void *stream)
+{
+    int rc;
+    void *lam = d_lambda ? d_lambda : s->lambda;
+    void *dz = d_dz ? d_dz : s->dz;
+    if ((rc = s->ops->add_rho(s->d, d_G_blocks, rho, s->G_dense, (hipStream_t)stream))) return rc;
+    if ((rc = gato_form_schur(s, s->G_dense, d_C_blocks, d_g, d_c, s->Sbd, s->Pbd, s->gamma, s->Ginv, stream))) return rc;
+    if ((rc = gato_form_ss(s, s->Sbd, s->Pbd, stream))) return rc;
+    if ((rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream))) return rc;
+    return gato_compute_dz(s, s->Ginv, d_C_blocks, d_g, lam, dz, stream);
+}
+
+extern "C" int gato_shard_pcg_done(gato_solver *s, int *done, void *stream)
+{
+    GATO_HIP_CHECK(hipMemcpyAsync(done, s->sw.done, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GATO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return GATO_OK;
+}
+
 extern "C" int gato_linsys_device_batched(gato_solver *s, const int *d_G_row, const int *d_G_col, const void *d_G_val,
                                           int nnz_G, const int *d_C_row, const int *d_C_col, const void *d_C_val,
                                           int nnz_C, const void *d_g, const void *d_c, double exit_tol, int max_iters,
@@ -551,6 +575,25 @@ static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const i
                   "(want %d), len(g)=%d (want %lld), len(c)=%d (want %d)",
                   S, C, K, len_G_row, N + 1, len_C_row, S * K + 1, len_g, N, len_c, S * K);
         return GATO_EINVAL;
+    }
+    // The scatter kernel trusts the CSR arrays (as the reference does, gato_schur.cuh:674-743); an out-of-range index
+    // would be an out-of-bounds device write, so the host copy is validated here (O(nnz), the arrays are in cache).
+    {
+        auto bad = [&](const char *name, const int *row, int nrows, const int *col, int nnz, long long ncols) -> bool {
+            if (row[0] != 0) { set_error("linsys_solve: %s_row[0] must be 0", name); return true; }
+            for (int i = 0; i < nrows; ++i)
+                if (row[i + 1] < row[i] || row[i + 1] > nnz) {
+                    set_error("linsys_solve: %s_row is not a monotone indptr at row %d", name, i);
+                    return true;
+                }
+            for (int i = 0; i < nnz; ++i)
+                if (col[i] < 0 || col[i] >= ncols) {
+                    set_error("linsys_solve: %s_col[%d] = %d is outside [0, %lld)", name, i, col[i], ncols);
+                    return true;
+                }
+            return false;
+        };
+        if (bad("G", G_row, len_G_row - 1, G_col, nnz_G, N) || bad("C", C_row, len_C_row - 1, C_col, nnz_C, N)) return GATO_EINVAL;
     }
     if (G_row[len_G_row - 1] != nnz_G || C_row[len_C_row - 1] != nnz_C) {
         set_error("linsys_solve: indptr[-1] does not match nnz (G %d vs %d, C %d vs %d)", G_row[len_G_row - 1], nnz_G,

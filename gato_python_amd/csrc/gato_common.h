@@ -143,6 +143,8 @@ template <typename T, int S, int C>
 int launch_convert(const Dims &d, const int *G_row, const int *G_col, const T *G_val, const int *C_row,
                    const int *C_col, const T *C_val, T rho, T *Gd, T *Cd, hipStream_t st);
 template <typename T, int S, int C>
+int launch_add_rho(const Dims &d, const T *G_in, T rho, T *Gd, hipStream_t st);
+template <typename T, int S, int C>
 int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const T *c, T *Sbd, T *Pbd,
                       T *gamma, T *Ginv, hipStream_t st);
 template <typename T, int S, int C>
@@ -205,6 +207,7 @@ struct Ops {
     int S, C, dtype;
     int (*convert)(const Dims &, const int *, const int *, const void *, const int *, const int *,
                    const void *, double, void *, void *, hipStream_t);
+    int (*add_rho)(const Dims &, const void *, double, void *, hipStream_t);
     int (*form_schur)(const Dims &, const void *, const void *, const void *, const void *, void *, void *,
                       void *, void *, hipStream_t);
     int (*form_ss)(const Dims &, const void *, void *, hipStream_t);

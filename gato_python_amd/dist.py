@@ -148,7 +148,9 @@ class HipShardBackend:
         return lam, iters
 
     def done(self):
-        raise NotImplementedError("host-side convergence polling is not wired for the HIP backend yet")
+        v = ct.c_int(0)
+        self._lib.check(self._lib.lib().gato_shard_pcg_done(self.sol._h, ct.byref(v), self._st()))
+        return v.value != 0
 
 
 def linsys_solve_sharded(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None):

@@ -118,6 +118,12 @@ class Solver:
                                                  int(max_iters), float(rho), _ptr(lam), _ptr(dz),
                                                  self._stream()))
 
+    def linsys_blocks(self, G_blocks, C_blocks, g, c, exit_tol, max_iters, rho, lam=None, dz=None):
+        """Direct block input: G_blocks / C_blocks in the G_dense / C_dense layouts, rho not yet added."""
+        _lib.check(_lib.lib().gato_linsys_device_blocks(self._h, _ptr(G_blocks), _ptr(C_blocks), _ptr(g), _ptr(c),
+                                                        float(exit_tol), int(max_iters), float(rho), _ptr(lam),
+                                                        _ptr(dz), self._stream()))
+
     def linsys_batched(self, G_row, G_col, G_val, C_row, C_col, C_val, g, c, exit_tol, max_iters, rho,
                        lam, dz, iters=None):
         """B systems with a shared CSR structure: G_val [B*nnzG], C_val [B*nnzC], g [B*N], c [B*S*K]."""

@@ -165,6 +165,17 @@ int gato_shard_pcg_phase_b(gato_solver *s, int it, const void *d_recvB_cur, cons
                            void *stream);
 int gato_shard_pcg_finish(gato_solver *s, const void *d_recvB_last, void *d_lambda_full_out, int *d_iters,
                           void *stream);
+/* Host-side convergence poll between iterations (synchronises `stream`): *done = 1 once the exit test has fired.
+ * Every rank computes the same sums, so every rank reads the same value. */
+int gato_shard_pcg_done(gato_solver *s, int *done, void *stream);
+
+/* ---- direct block input (new): the caller already holds the per-knot blocks in the
+ * reference's dense layouts - d_G_blocks as G_dense WITHOUT rho, d_C_blocks as C_dense - so the CSR scatter is
+ * skipped; rho is added to the diagonals of Q_k, R_k on the way into the solver's workspace.  Otherwise identical
+ * to gato_linsys_device (batched solvers take B systems back to back). */
+int gato_linsys_device_blocks(gato_solver *s, const void *d_G_blocks, const void *d_C_blocks, const void *d_g,
+                              const void *d_c, double exit_tol, int max_iters, double rho, void *d_lambda, void *d_dz,
+                              void *stream);
 
 #ifdef __cplusplus
 }

@@ -103,3 +103,19 @@ def test_pybind11_module_builds_and_imports():
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "bindings", "pybind11", "build"))
     r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_malformed_csr_is_rejected_on_the_host():
+    """Out-of-range CSR indices would be out-of-bounds device writes in the scatter: refused before any launch."""
+    import gpu_library
+    P = dict(synth.PENDULUM)
+    bad_col = list(P["C_col"])
+    bad_col[5] = 99
+    with pytest.raises(ValueError, match="outside"):
+        gpu_library.linsys_solve(P["G_row"], P["G_col"], P["G_val"], P["C_row"], bad_col, P["C_val"], P["g_val"],
+                                 P["c_val"], P["input_lambda"], 1, 1e-6, 10, False, 1e-3)
+    bad_row = list(P["G_row"])
+    bad_row[3] = 1
+    with pytest.raises(ValueError, match="monotone|indptr"):
+        gpu_library.linsys_solve(bad_row, P["G_col"], P["G_val"], P["C_row"], P["C_col"], P["C_val"], P["g_val"],
+                                 P["c_val"], P["input_lambda"], 1, 1e-6, 10, False, 1e-3)

@@ -388,3 +388,29 @@ def test_random_resident_geometries():
         assert int(host(it)[0]) == it_o, (K, threads, groups, int(host(it)[0]), it_o)
         assert rel(host(lam), lam_o) < 1e-8, (K, threads, groups)   # summation order differs with the split
         sol.close()
+
+
+def test_c_host_example():
+    """examples/solve_pendulum.c: the reference's test case from plain C over the C ABI (no Python in the path)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "-s"])
+    r = subprocess.run([os.path.join(root, "examples", "solve_pendulum")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "Test passed" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("S,C,K,dt,dq", [(14, 7, 50, np.float64, False), (14, 7, 9, np.float32, True), (32, 16, 5, np.float64, True)])
+def test_direct_block_input(S, C, K, dt, dq):
+    """per-knot blocks handed over in the dense layouts (no CSR scatter) give the same
+    (lambda, dz) as the CSR path."""
+    s = synth.make_system(S, C, K, seed=31, dense_q=dq)
+    Gd0, Cd = co.convert(*s.csr_args()[:6], S, C, K, 0.0, dt)            # blocks without rho
+    sol = make_solver(S, C, K, dt)
+    f64 = dt == np.float64
+    tol, mi = (1e-10, 300) if f64 else (1e-5, 100)
+    lam, dz = sol.new(S * K), sol.new(sol.N)
+    sol.linsys_blocks(sol.to_device(Gd0), sol.to_device(Cd), sol.to_device(s.g), sol.to_device(s.c), tol, mi, s.rho, lam, dz)
+    torch.cuda.synchronize()
+    lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
+    assert rel(host(lam), lam_o) < (1e-8 if f64 else 5e-3) and rel(host(dz), dz_o) < (1e-8 if f64 else 5e-3)
+    sol.close()

@@ -40,6 +40,7 @@ def test_shard_kernels_lockstep(S, C, K, R, dt):
     assert len(set(its)) == 1 and abs(its[0] - it_o) <= (0 if f64 else 2), (its, it_o)
     err = np.abs(lam.cpu().numpy() - lam_o).max() / np.abs(lam_o).max()
     assert err < (1e-9 if f64 else 5e-3), err
+    assert all(b.done() for b in bes) == (its[0] < mi)              # the host-side convergence poll agrees
     for x in sols:
         x.close()
 
