@@ -43,6 +43,7 @@ WORKLOADS = {
     "iiwa_14_7_k131072_f32": (14, 7, 131072, np.float32, "K beyond residency, streaming kernel (HBM-roofline run)"),
 }
 MAX_ITERS = 100
+PCG_VARIANT = 0     # 1 = opt-in single-reduction (Chronopoulos-Gear) resident kernel, sweep entries only
 
 
 def b_iter(S, K, w):
@@ -53,8 +54,9 @@ def dtype_name(dt):
     return "f64" if np.dtype(dt) == np.float64 else "f32"
 
 
-def run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, max_iters=None):
-    global MAX_ITERS
+def run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, max_iters=None, variant=0):
+    global MAX_ITERS, PCG_VARIANT
+    PCG_VARIANT = variant
     saved = MAX_ITERS
     if max_iters is not None:
         MAX_ITERS = max_iters
@@ -72,6 +74,8 @@ def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20):
     sol = Solver(S, C, K, dt)
     if pcg_mode is not None:
         sol.set_option("pcg_mode", pcg_mode)
+    if PCG_VARIANT:
+        sol.set_option("pcg_variant", PCG_VARIANT)
     dev = sol.upload_system(sysm)
     lam, dz = sol.new(S * K), sol.new(sol.N)
 
@@ -239,6 +243,12 @@ def main():
                 r = r2
             r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
             r["hbm_bytes_per_launch_pmc"] = committed_traffic(other)
+            sweep.append(r)
+        # opt-in single-reduction variant (one hand-off per iteration; rounding differs from the reference recurrence)
+        for other in ("iiwa_14_7_k512_f32", "iiwa_14_7_k4096_f32", "s32_c16_k1024_f32"):
+            r, _ = run_single(other, max(10, args.steps // 10), 3, torch, variant=1)
+            r["workload"] += "_single_reduction_variant"
+            r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
             sweep.append(r)
         # batches of independent systems: throughput mode of the K=50 shape
         sweep.append(run_batched(14, 7, 50, np.float64, 512, 10, 2, torch))

@@ -47,6 +47,8 @@ static Ops make_ops(int dtype)
     };
     o.pcg_plan = [](PcgPlan *p) { return pcg_resident_plan<T, S>(p); };
     o.pcg_resident = [](const PcgLaunch &a, hipStream_t st) { return launch_pcg_resident<T, S>(a, st); };
+    o.pcg_cg1_max_threads = []() { return pcg_cg1_max_threads<T, S>(); };
+    o.pcg_cg1 = [](const PcgLaunch &a, hipStream_t st) { return launch_pcg_cg1<T, S>(a, st); };
     o.stream_grid = [](int K, int mg) { return stream_grid<T, S>(K, mg); };
     o.stream_step = [](int ph, const StreamStep &a, int grid, hipStream_t st) { return launch_stream_step<T, S>(ph, a, grid, st); };
     o.stream_pack = [](const void *sl, int n, const void *y, int K, void *send, hipStream_t st) {
@@ -112,8 +114,8 @@ struct gato_solver {
     size_t in_bytes;
     char *pin;            // pinned host staging (inputs, then iters | lambda | dz)
     size_t pin_bytes;
-    int last_groups, last_threads, last_mode;
-    int time_pcg, stamp_pcg, ablate, no_single_lds, true_warm_start, no_pair, plan_pair;
+    int last_groups, last_threads, last_mode, last_variant;
+    int time_pcg, stamp_pcg, ablate, no_single_lds, true_warm_start, no_pair, plan_pair, pcg_variant;
     hipEvent_t ev_pcg0, ev_pcg1;
     // knot-sharded PCG state (gato_shard_pcg_*)
     struct {
@@ -251,7 +253,9 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 8); return o; };
     // status block first, granules right behind it: one memset re-initialises both before a launch
     const size_t o_status = take(64);
-    const size_t o_slots = take((size_t)2 * 256 * pcg_slot_granules(S, (int)e) * 8);
+    const int slot_g = pcg_slot_granules(S, (int)e) > pcg_slot_granules_cg1(S, (int)e) ? pcg_slot_granules(S, (int)e)
+                                                                                        : pcg_slot_granules_cg1(S, (int)e);
+    const size_t o_slots = take((size_t)2 * 256 * slot_g * 8);
     const size_t nb = (size_t)B;
     const size_t o_G = take(d.g_dense() * e * nb), o_C = take(d.c_dense() * e * nb), o_Gi = take(d.g_dense() * e * nb);
     const size_t o_S = take(d.bd() * e * nb), o_P = take(d.bd() * e * nb), o_gam = take(d.sk() * e * nb);
@@ -317,6 +321,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "ablate")) s->ablate = value;
     else if (!strcmp(name, "no_single_lds")) s->no_single_lds = value;
     else if (!strcmp(name, "no_pair")) s->no_pair = value;
+    else if (!strcmp(name, "pcg_variant")) s->pcg_variant = value;
     else if (!strcmp(name, "true_warm_start")) s->true_warm_start = value;
     else if (!strcmp(name, "batch_nnz_G")) s->d.nnzG = value;
     else if (!strcmp(name, "batch_nnz_C")) s->d.nnzC = value;
@@ -348,6 +353,7 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "last_threads")) *value = s->last_threads;
     else if (!strcmp(name, "last_mode")) *value = s->last_mode;
     else if (!strcmp(name, "last_pair")) *value = s->plan_pair;
+    else if (!strcmp(name, "last_variant")) *value = s->last_variant;
     else if (!strcmp(name, "num_cus")) *value = s->num_cus;
     else if (!strcmp(name, "batch")) *value = s->d.B;
     else if (!strcmp(name, "max_resident_knots")) *value = s->plan.max_knots_per_wg * (s->num_cus < 256 ? s->num_cus : 256);
@@ -431,12 +437,44 @@ static int plan_resident(gato_solver *s, int *groups, int *threads, int *kpw)
     return 1;
 }
 
+// Geometry of the single-reduction variant: a workgroup's lanes cover its own knots plus one ghost-lane knot per side.
+static int plan_cg1(gato_solver *s, int *groups, int *threads, int *kpw)
+{
+    const int S = s->d.S, K = s->d.K;
+    const int max_wg = s->num_cus < 256 ? s->num_cus : 256;
+    const int maxT = s->ops->pcg_cg1_max_threads();
+    int t = s->pcg_threads > 0 ? (s->pcg_threads + 63) / 64 * 64 : 0;
+    if (t > maxT) t = maxT;
+    if (t == 0) {
+        if ((K + 2) * S <= maxT) t = ((K + 2) * S + 63) / 64 * 64;
+        else {
+            t = maxT < 512 ? maxT : 512;
+            while (t < maxT && (K + (t / S - 2) - 1) / (t / S - 2) > max_wg) t += 64;
+        }
+    }
+    if (t < 4 * S) t = (4 * S + 63) / 64 * 64;
+    if (t > maxT) return 0;
+    const int per = t / S - 2;
+    if (per < 2) return 0;
+    int W = (K + per - 1) / per;
+    if (s->pcg_groups > W) W = s->pcg_groups;
+    if (W > max_wg) return 0;
+    int k_per = (K + W - 1) / W;
+    W = (K + k_per - 1) / k_per;
+    if (W > 1 && (k_per < 2 || K - (W - 1) * k_per < 2)) return 0;
+    *groups = W; *threads = t; *kpw = k_per;
+    return 1;
+}
+
 static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
                    double exit_tol, int max_iters, int *d_iters, int batch, hipStream_t st)
 {
     int groups = 0, threads = 0, kpw = 0;
     int mode = s->pcg_mode;
-    const bool fits = plan_resident(s, &groups, &threads, &kpw) != 0;
+    const bool cg1 = s->pcg_variant == 1 && mode != GATO_PCG_STREAMING && !s->true_warm_start &&
+                     plan_cg1(s, &groups, &threads, &kpw) != 0 && (batch == 1 || groups == 1);
+    const bool fits = cg1 || plan_resident(s, &groups, &threads, &kpw) != 0;
+    if (cg1) s->plan_pair = 0;
     if (mode == GATO_PCG_AUTO) mode = fits ? GATO_PCG_RESIDENT : GATO_PCG_STREAMING;
     if (mode == GATO_PCG_RESIDENT) {
         if (!fits) {
@@ -460,7 +498,8 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.ev_start = s->time_pcg ? s->ev_pcg0 : nullptr;
         a.ev_stop = s->time_pcg ? s->ev_pcg1 : nullptr;
         s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT;
-        return s->ops->pcg_resident(a, st);
+        s->last_variant = cg1 ? 1 : 0;
+        return cg1 ? s->ops->pcg_cg1(a, st) : s->ops->pcg_resident(a, st);
     }
     s->last_mode = GATO_PCG_STREAMING; s->last_groups = 0; s->last_threads = 0;
     s->sw.warm_start = s->true_warm_start;

@@ -131,6 +131,13 @@ __host__ __device__ inline int pcg_slot_granules(int S, int esz)
     return 16 + ((halo + 15) / 16) * 16;
 }
 
+// Hand-off slot of the single-reduction variant: line 0 = {gamma', delta}, then the first two and last two S-blocks of w.
+__host__ __device__ inline int pcg_slot_granules_cg1(int S, int esz)
+{
+    int gpv = esz / 4;
+    return 16 + ((4 * S * gpv + 15) / 16) * 16;
+}
+
 struct PcgPlan {
     int max_threads;     // launch bound of the instantiation
     int max_knots_per_wg;
@@ -156,6 +163,9 @@ template <typename T, int S>
 int pcg_resident_plan(PcgPlan *plan);
 template <typename T, int S>
 int launch_pcg_resident(const PcgLaunch &a, hipStream_t st);
+template <typename T, int S> int pcg_cg1_max_threads();
+template <typename T, int S>
+int launch_pcg_cg1(const PcgLaunch &a, hipStream_t st);
 
 // Streaming PCG (two launches per iteration), gato_pcg_stream.hip
 struct PcgStreamWork {
@@ -215,6 +225,8 @@ struct Ops {
                       hipStream_t);
     int (*pcg_plan)(PcgPlan *);
     int (*pcg_resident)(const PcgLaunch &, hipStream_t);
+    int (*pcg_cg1_max_threads)();
+    int (*pcg_cg1)(const PcgLaunch &, hipStream_t);
     int (*pcg_streaming)(const Dims &, const void *, const void *, const void *, void *, double, int, int *,
                          const PcgStreamWork &, hipStream_t);
     int (*stream_grid)(int, int);

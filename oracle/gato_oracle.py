@@ -250,6 +250,44 @@ def pcg(S_bd, Pinv_bd, gamma, S, K, exit_tol, max_iters, return_history=False, l
     return lam.reshape(-1), iters
 
 
+def pcg_single_reduction(S_bd, Pinv_bd, gamma, S, K, exit_tol, max_iters):
+    """Chronopoulos-Gear single-reduction PCG - NOT the reference's recurrence; restated here only to check the opt-in
+    HIP variant (gato_pcg_cg1.hip).  Same exit test quantity (r . Pinv r) and iteration numbering as pcg()."""
+    dtype = S_bd.dtype
+    Sl, Sm, Sr = unpack_bd(S_bd, S, K)
+    Pl, Pm, Pr = unpack_bd(Pinv_bd, S, K)
+    lam = np.zeros((K, S), dtype)
+    r = np.asarray(gamma, dtype).reshape(K, S).copy()
+    u = bt_matvec(Pl, Pm, Pr, r)
+    w = bt_matvec(Sl, Sm, Sr, u)
+    gam = dtype.type(np.sum(r * u, dtype=dtype))
+    delta = dtype.type(np.sum(w * u, dtype=dtype))
+    p = np.zeros_like(r)
+    s = np.zeros_like(r)
+    beta = dtype.type(0)
+    with np.errstate(all="ignore"):
+        alpha = gam / delta
+    iters = max_iters
+    tol = dtype.type(exit_tol)
+    for it in range(max_iters):
+        p = u + beta * p
+        s = w + beta * s
+        lam = lam + alpha * p
+        r = r - alpha * s
+        u = bt_matvec(Pl, Pm, Pr, r)
+        w = bt_matvec(Sl, Sm, Sr, u)
+        gam_new = dtype.type(np.sum(r * u, dtype=dtype))
+        delta = dtype.type(np.sum(w * u, dtype=dtype))
+        if abs(gam_new) < tol:
+            iters = it
+            break
+        with np.errstate(all="ignore"):
+            beta = gam_new / gam
+            alpha = gam_new / (delta - beta * gam_new / alpha)
+        gam = gam_new
+    return lam.reshape(-1), iters
+
+
 # --------------------------------------------------------------------------------------------
 # A9: dz back-substitution                        (src/gato_schur.cuh:758-867, D2 fixed)
 # --------------------------------------------------------------------------------------------

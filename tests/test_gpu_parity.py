@@ -414,3 +414,35 @@ def test_direct_block_input(S, C, K, dt, dq):
     lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
     assert rel(host(lam), lam_o) < (1e-8 if f64 else 5e-3) and rel(host(dz), dz_o) < (1e-8 if f64 else 5e-3)
     sol.close()
+
+
+@pytest.mark.parametrize("S,C,K,dt,opts", [(14, 7, 50, np.float64, {}), (14, 7, 50, np.float32, {}),
+                                           (14, 7, 50, np.float64, dict(pcg_threads=192)),       # 10 knots per workgroup
+                                           (14, 7, 512, np.float64, {}), (14, 7, 512, np.float32, {}),
+                                           (14, 7, 4096, np.float32, {}), (14, 7, 4096, np.float64, {}),
+                                           (32, 16, 300, np.float64, {}), (2, 1, 900, np.float64, dict(pcg_threads=64))])
+def test_single_reduction_variant(S, C, K, dt, opts):
+    """Opt-in Chronopoulos-Gear variant (one hand-off per iteration): equals its own numpy restatement to rounding,
+    and the reference recurrence's solution to solver tolerance; iteration counts within one of each other."""
+    s = synth.make_system(S, C, K, seed=23)
+    Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
+    Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+    Pb = co.form_ss(Sb, Pb, S, K)
+    f64 = dt == np.float64
+    tol = 1e-9 if f64 else 1e-4
+    lam_cg, it_cg = o.pcg_single_reduction(Sb, Pb, gam, S, K, tol, 300)
+    lam_ref, it_ref = co.pcg(Sb, Pb, gam, S, K, tol, 300)
+    sol = make_solver(S, C, K, dt)
+    sol.set_option("pcg_variant", 1)
+    for k, v in opts.items():
+        sol.set_option(k, v)
+    dS, dP, dg = sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam)
+    lam, it = sol.pcg(dS, dP, dg, tol, 300)
+    assert sol.get_option("last_variant") == 1
+    assert abs(int(host(it)[0]) - it_cg) <= (0 if f64 else 2), (int(host(it)[0]), it_cg, it_ref)
+    assert abs(int(host(it)[0]) - it_ref) <= 2
+    assert rel(host(lam), lam_cg) < (1e-8 if f64 else 5e-3)
+    assert rel(host(lam), lam_ref) < (1e-6 if f64 else 5e-3)
+    lam2, it2 = sol.pcg(dS, dP, dg, tol, 300)
+    assert torch.equal(lam, lam2) and torch.equal(it, it2)        # deterministic
+    sol.close()
