@@ -15,7 +15,9 @@
 #ifndef GATO_EXTRA_SHAPES
 #define GATO_EXTRA_SHAPES(X)
 #endif
-#define GATO_SHAPES(X) X(2, 1) X(14, 7) X(32, 16) GATO_EXTRA_SHAPES(X)
+// default build: pendulum (2/1, the reference's test), IIWA-14 (14/7, its default), 32/16 (BASELINE config 5) and a few
+// common robot sizes
+#define GATO_SHAPES(X) X(2, 1) X(14, 7) X(32, 16) X(4, 2) X(6, 3) X(12, 6) GATO_EXTRA_SHAPES(X)
 
 namespace gato {
 

@@ -70,8 +70,20 @@ def main(args):
         sol.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
         torch.cuda.synchronize()
         den = float(lam1.abs().max())
+        # the same system on ONE GPU with the register-resident kernel, timed here so that the strong-scaling ratio of
+        # this line can be read off without comparing against bench.py's N=1 workload (a different shape)
+        for _ in range(3):
+            sol.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n1 = 20
+        for _ in range(n1):
+            sol.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
+        torch.cuda.synchronize()
+        single = MAX_ITERS * n1 / (time.perf_counter() - t1)
         parity = {"lam_rel_err_vs_single_gpu": float((lam - lam1).abs().max()) / den,
-                  "dz_abs_err_vs_single_gpu": float((dz - dz1).abs().max()), "iters": int(iters.cpu()[0])}
+                  "dz_abs_err_vs_single_gpu": float((dz - dz1).abs().max()), "iters": int(iters.cpu()[0]),
+                  "same_system_on_one_gpu_resident_iters_per_s": single}
     if rank == 0:
         w = np.dtype(dt).itemsize
         b_iter = ((6 * K - 4) * S * S + 13 * S * K) * w

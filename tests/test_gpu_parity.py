@@ -446,3 +446,21 @@ def test_single_reduction_variant(S, C, K, dt, opts):
     lam2, it2 = sol.pcg(dS, dP, dg, tol, 300)
     assert torch.equal(lam, lam2) and torch.equal(it, it2)        # deterministic
     sol.close()
+
+
+@pytest.mark.parametrize("S,C,K", [(4, 2, 30), (6, 3, 100), (12, 6, 64), (12, 6, 700)])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_other_compiled_shapes(S, C, K, dt):
+    """The extra (STATE_SIZE, CONTROL_SIZE) instantiations of the default build: whole solve vs the oracle."""
+    s = synth.make_system(S, C, K, seed=41, dense_q=True)
+    sol = make_solver(S, C, K, dt)
+    dev = sol.upload_system(s)
+    f64 = dt == np.float64
+    tol, mi = (1e-10, 400) if f64 else (1e-5, 150)
+    lam, dz = sol.new(S * K), sol.new(sol.N)
+    sol.linsys(*dev, tol, mi, s.rho, lam, dz)
+    torch.cuda.synchronize()
+    sol.check_status()
+    lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
+    assert rel(host(lam), lam_o) < (1e-8 if f64 else 5e-3) and rel(host(dz), dz_o) < (1e-8 if f64 else 5e-3)
+    sol.close()
