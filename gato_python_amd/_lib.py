@@ -27,7 +27,7 @@ SYMBOLS = [
     "gato_form_ss", "gato_pcg", "gato_pcg_status", "gato_pcg_last_ms", "gato_compute_dz", "gato_linsys_device",
     "gato_linsys_solve_f32", "gato_linsys_solve_f64",
     "gato_shard_pcg_init", "gato_shard_pcg_phase_a", "gato_shard_pcg_phase_b", "gato_shard_pcg_finish",
-    "gato_shard_pcg_done", "gato_linsys_device_blocks",
+    "gato_shard_pcg_done", "gato_linsys_device_blocks", "gato_release_cache",
 ]
 
 
@@ -48,6 +48,11 @@ def build(force: bool = False) -> str:
 def lib() -> ct.CDLL:
     global _LIB
     if _LIB is None:
+        if not os.path.exists(SO_PATH) and "GATO_HIP_LIB" not in os.environ:
+            try:                       # source tree without the built library: compile it (hipcc, ~10 s); no fallback
+                build()
+            except Exception as e:     # noqa: BLE001
+                raise ImportError(f"{SO_PATH} is missing and building it failed: {e}") from e
         if not os.path.exists(SO_PATH):
             raise ImportError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

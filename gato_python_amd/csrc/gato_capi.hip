@@ -598,6 +598,17 @@ extern "C" int gato_linsys_device_batched(gato_solver *s, const int *d_G_row, co
     return GATO_OK;
 }
 
+static std::mutex g_cache_mu;
+static gato_solver *g_cached_solver = nullptr;
+
+extern "C" int gato_release_cache(void)
+{
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    if (g_cached_solver) gato_solver_destroy(g_cached_solver);
+    g_cached_solver = nullptr;
+    return GATO_OK;
+}
+
 // ---- host-pointer drop-in for main_call (gpu_library.cu:85-234) -----------------------------------
 template <typename T>
 static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const int *G_col, const T *G_val, int nnz_G,
@@ -641,9 +652,8 @@ static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const i
     }
     // The reference allocates and frees 22 device buffers per call (gpu_library.cu:36-45,140-147; gato_pcg.cuh:486-492).
     // Here the solver of the most recent (S, C, K, dtype) and its input staging area are kept for the next call.
-    static std::mutex cache_mu;
-    static gato_solver *cached = nullptr;
-    std::lock_guard<std::mutex> lock(cache_mu);
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    gato_solver *&cached = g_cached_solver;
     gato_solver *s = cached;
     int rc;
     if (!s || s->d.S != S || s->d.C != C || s->d.K != K || s->dtype != dtype || s->d.B != 1) {

@@ -134,6 +134,9 @@ int gato_linsys_solve_f32(const int *G_row, int len_G_row, const int *G_col, con
                           int S, int C, int K, int testiters, float exit_tol, int max_iters,
                           int warm_start, float rho, float *lambda_out, float *dz_out,
                           int *iters_out, float *ms_out);
+/* The host entries keep the solver and staging buffers of the most recent (S, C, K, dtype) for the next call;
+ * gato_release_cache() frees them (optional; e.g. before unloading the library). */
+int gato_release_cache(void);
 int gato_linsys_solve_f64(const int *G_row, int len_G_row, const int *G_col, const double *G_val, int nnz_G,
                           const int *C_row, int len_C_row, const int *C_col, const double *C_val, int nnz_C,
                           const double *g, int len_g, const double *c, int len_c, const double *lambda_in,
