@@ -65,22 +65,6 @@ __device__ __forceinline__ double lane63(double v)
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-#ifdef GATO_MFMA_WAVESUM
-// fp64 has no DPP add (each DPP step is two moves + an add + hazard nops): fold the four 16-lane rows with ONE
-// v_mfma_f64_16x16x4 (A = ones: D[i][j] = sum_k v[16k + j]), then four intra-row DPP steps.
-__device__ __forceinline__ double wave_sum_dpp(double v)
-{
-    typedef double d4 __attribute__((ext_vector_type(4)));
-    d4 c = {0, 0, 0, 0};
-    c = __builtin_amdgcn_mfma_f64_16x16x4f64(1.0, v, c, 0, 0, 0);
-    double s = c[0];
-    s += dpp_mov<0xB1, 0xf>(s);
-    s += dpp_mov<0x4E, 0xf>(s);
-    s += dpp_mov<0x141, 0xf>(s);
-    s += dpp_mov<0x140, 0xf>(s);
-    return lane63(s);
-}
-#endif
 template <typename T>
 __device__ __forceinline__ T wave_sum_dpp(T v)
 {
