@@ -16,3 +16,14 @@ for (S, C, K) in [(2, 1, 5), (14, 7, 50), (14, 7, 512)]:
         dt = (time.perf_counter() - t0) / n
         st = gpu_library.last_stats()
         print(f"{S}/{C}/{K} {name}: {dt*1e3:.3f} ms per call (device-timed solve {st['ms'][0]:.3f} ms, iters {st['iters']})", flush=True)
+
+# PCIe-inclusive rate of the bench workload (BASELINE configs[1]: 14/7/50, f64, exactly 100 iterations)
+gpu_library.set_precision("f64")
+s = synth.make_system(14, 7, 50, seed=0)
+args = (s.G_row, s.G_col, s.G_val, s.C_row, s.C_col, s.C_val, s.g, s.c, np.zeros(700), 1, 0.0, 100, False, s.rho)
+for _ in range(5): gpu_library.linsys_solve(*args)
+t0 = time.perf_counter(); n = 50
+for _ in range(n): gpu_library.linsys_solve(*args)
+dt = (time.perf_counter() - t0) / n
+print(f"bench workload through the host boundary (numpy in, lists out): {dt*1e3:.3f} ms per call = {100/dt:.0f} PCG iterations/s PCIe-inclusive "
+      f"(device-timed {gpu_library.last_stats()['ms'][0]:.3f} ms)")
