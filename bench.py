@@ -14,7 +14,8 @@ B_iter = [(6K-4) S^2 + 13 S K] w x iterations / launch ti
 
 N = 1 runs BASELINE.json configs[1] (IIWA 14/7, K = 50, fp64).  N > 1 runs configs[3]: one K = 4096
 system with its knots sharded over the N ranks (RCCL all-gathers of [partial dot | boundary blocks],
-gato_python_amd/dist.py), strong scaling.
+gato_python_amd/dist.py), strong scaling.  `--workload batched_512x_f64` (any N) runs independent batches per rank instead
+(weak scaling, no collective).
 """
 from __future__ import annotations
 
@@ -205,7 +206,7 @@ def main():
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or (args.workload or "").startswith("sharded"):
+    if args.gpus > 1 or world > 1 or (args.workload or "").startswith(("sharded", "batched")):
         from gato_python_amd import dist_bench
         return dist_bench.main(args)
 

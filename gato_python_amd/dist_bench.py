@@ -19,6 +19,45 @@ WORKLOADS = {"sharded_k4096_f32": (14, 7, 4096, np.float32), "sharded_k4096_f64"
              "sharded_k262144_f32": (14, 7, 262144, np.float32)}
 
 
+def main_batched(args, torch, dist, rank, local, world):
+    """--workload batched_*: every rank solves its own batch of independent 14/7/50 systems, no data-path
+    collective - the weak-scaling mode in which more GPUs do pay for this shape."""
+    from . import synth
+    from .solver import Solver
+    S, C, K, B = 14, 7, 50, 512
+    dt = np.float32 if args.workload.endswith("f32") else np.float64
+    base = synth.make_system(S, C, K, seed=rank)
+    sol = Solver(S, C, K, dt, local, batch=B)
+    dev = sol.upload_batch([base] * B)
+    lam, dz = sol.new(B * S * K), sol.new(B * sol.N)
+    iters = sol.new(B, torch.int32)
+    step = lambda: sol.linsys_batched(*dev, 0.0, MAX_ITERS, base.rho, lam, dz, iters)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+    if rank == 0:
+        val = MAX_ITERS * B * world * args.steps / el
+        print(json.dumps({"metric": "PCG iterations/s", "value": val, "unit": "iterations/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f64" if dt == np.float64 else "f32", "data": "synthetic",
+                          "config": {"workload": args.workload, "STATE_SIZE": S, "CONTROL_SIZE": C, "KNOT_POINTS": K,
+                                     "systems_per_gpu": B, "max_iters": MAX_ITERS, "exit_tol": 0.0,
+                                     "parallelism": f"independent batches x{world}, no collective"}}))
+    dist.destroy_process_group()
+
+
 def main(args):
     import torch
     import torch.distributed as dist
@@ -33,6 +72,8 @@ def main(args):
     os.environ.setdefault("MASTER_PORT", "29500")
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if (args.workload or "").startswith("batched"):
+        return main_batched(args, torch, dist, rank, local, world)
     name = args.workload if args.workload in WORKLOADS else "sharded_k4096_f32"
     S, C, K, dt = WORKLOADS[name]
     sysm = synth.make_system(S, C, K, seed=0)

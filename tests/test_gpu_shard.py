@@ -54,3 +54,12 @@ def test_bench_sharded_leg_world1():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["workload"].startswith("sharded")
     assert d["parity"]["lam_rel_err_vs_single_gpu"] < 5e-3
+
+
+def test_bench_batched_leg_world1():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "batched_512x_f64",
+                        "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["scaling"] == "weak" and d["value"] > 1e6 and d["config"]["systems_per_gpu"] == 512
