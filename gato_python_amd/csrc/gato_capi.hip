@@ -366,6 +366,11 @@ extern "C" int gato_convert(gato_solver *s, const int *d_G_row, const int *d_G_c
                             const int *d_C_row, const int *d_C_col, const void *d_C_val, double rho,
                             void *d_G_dense, void *d_C_dense, void *stream)
 {
+    if (s->d.B > 1 && (s->d.nnzG <= 0 || s->d.nnzC <= 0)) {
+        set_error("convert: a batched solver needs the per-system nnz (gato_linsys_device_batched, or options "
+                  "batch_nnz_G / batch_nnz_C)");
+        return GATO_EINVAL;
+    }
     return s->ops->convert(s->d, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, rho, d_G_dense, d_C_dense,
                            (hipStream_t)stream);
 }
