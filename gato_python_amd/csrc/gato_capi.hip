@@ -55,8 +55,8 @@ static Ops make_ops(int dtype)
         return launch_stream_pack<T, S>(sl, n, y, K, send, st);
     };
     o.stream_finish = [](const void *part, int n, int stride, double tol, int last_it, int *done, int *iters,
-                         double *fe, hipStream_t st) {
-        return launch_stream_finish<T, S>(part, n, stride, tol, last_it, done, iters, fe, st);
+                         double *fe, double *hist, hipStream_t st) {
+        return launch_stream_finish<T, S>(part, n, stride, tol, last_it, done, iters, fe, hist, st);
     };
     o.pcg_streaming = [](const Dims &d, const void *Sb, const void *Pb, const void *gam, void *lam, double tol,
                          int max_iters, int *iters, const PcgStreamWork &w, hipStream_t st) {
@@ -91,6 +91,8 @@ const Ops *find_ops(int S, int C, int dtype)
 
 using namespace gato;
 
+#define GATO_ETA_HIST_MAX 4096
+
 // ---- solver object -----------------------------------------------------------------------------
 struct gato_solver {
     Dims d;
@@ -124,6 +126,8 @@ struct gato_solver {
         const char *S_full, *P_full, *gamma_full;
     } sh;
     char *ghosts;   // [r|p][ping-pong][left|right][S]
+    double *eta_hist;   // eta after init and after every iteration (option record_eta), GATO_ETA_HIST_MAX + 1 entries
+    int record_eta;
 };
 
 static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -264,6 +268,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     const size_t o_vec = take(6 * d.sk() * e);
     const size_t o_part = take((size_t)4 * max_groups * e), o_scal = take(64 * 8), o_done = take(64);
     const size_t o_gh = take((size_t)8 * S * e);
+    const size_t o_hist = take(sizeof(double) * (GATO_ETA_HIST_MAX + 1));
     s->arena_bytes = off;
     GATO_HIP_CHECK(hipMalloc((void **)&s->arena, off));
     GATO_HIP_CHECK(hipMemset(s->arena, 0, off));
@@ -278,6 +283,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     s->sw.partials = a + o_part; s->sw.scalars = a + o_scal; s->sw.done = (int *)(a + o_done);
     s->sw.max_groups = max_groups;
     s->ghosts = a + o_gh;
+    s->eta_hist = (double *)(a + o_hist);
     *out = s;
     return GATO_OK;
 }
@@ -308,6 +314,7 @@ extern "C" void *gato_solver_buffer(gato_solver *s, int which)
         case 7: return s->dz;
         case 8: return s->iters;
         case 9: return (unsigned long long *)s->sw.scalars + 8;   // diagnostic stamps (option stamp_pcg)
+        case 10: return s->eta_hist;                              // double[max_iters + 1] (option record_eta)
         default: return nullptr;
     }
 }
@@ -322,6 +329,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "no_single_lds")) s->no_single_lds = value;
     else if (!strcmp(name, "no_pair")) s->no_pair = value;
     else if (!strcmp(name, "pcg_variant")) s->pcg_variant = value;
+    else if (!strcmp(name, "record_eta")) s->record_eta = value;
     else if (!strcmp(name, "true_warm_start")) s->true_warm_start = value;
     else if (!strcmp(name, "batch_nnz_G")) s->d.nnzG = value;
     else if (!strcmp(name, "batch_nnz_C")) s->d.nnzC = value;
@@ -497,6 +505,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
         a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
         a.final_eta = s->final_eta;
+        a.eta_hist = (s->record_eta && max_iters <= GATO_ETA_HIST_MAX) ? s->eta_hist : nullptr;
         a.timeout_ticks = 200000000ull;   // 2 s at 100 MHz
         a.ablate = s->ablate;
         a.stamps = s->stamp_pcg ? (unsigned long long *)s->sw.scalars + 8 : nullptr;
@@ -508,6 +517,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
     }
     s->last_mode = GATO_PCG_STREAMING; s->last_groups = 0; s->last_threads = 0;
     s->sw.warm_start = s->true_warm_start;
+    s->sw.eta_hist = (s->record_eta && max_iters <= GATO_ETA_HIST_MAX) ? s->eta_hist : nullptr;
     if (s->time_pcg) GATO_HIP_CHECK(hipEventRecord(s->ev_pcg0, st));
     int rc = s->ops->pcg_streaming(s->d, d_S, d_Pinv, d_gamma, d_lambda, exit_tol, max_iters,
                                    d_iters ? d_iters : s->iters, s->sw, st);
@@ -877,7 +887,7 @@ extern "C" int gato_shard_pcg_finish(gato_solver *s, const void *d_recvB_last, v
 {
     hipStream_t st = (hipStream_t)stream;
     int rc = s->ops->stream_finish(d_recvB_last, s->sh.nranks, 2 * s->d.S + 1, s->sh.exit_tol, s->sh.max_iters - 1,
-                                   s->sw.done, s->iters, s->final_eta, st);
+                                   s->sw.done, s->iters, s->final_eta, nullptr, st);
     if (rc) return rc;
     if (d_lambda_full_out && d_lambda_full_out != s->lambda)
         GATO_HIP_CHECK(hipMemcpyAsync(d_lambda_full_out, s->lambda, s->d.sk() * s->esz, hipMemcpyDeviceToDevice, st));

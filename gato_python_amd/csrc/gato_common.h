@@ -118,6 +118,7 @@ struct PcgLaunch {
     int *iters;                  // device
     int *status;                 // device, 0 ok / 1 timeout
     double *final_eta;           // device (optional)
+    double *eta_hist;            // device (optional): eta after init [0] and after iteration i [i+1] (system 0 of a batch)
     unsigned long long timeout_ticks;  // s_memrealtime ticks (100 MHz)
     hipEvent_t ev_start, ev_stop;      // optional: recorded right around the kernel launch
     int ablate;                        // diagnostic: timing-only ablation mask (0 in production)
@@ -177,6 +178,7 @@ struct PcgStreamWork {
     int *done;                     // device flag
     int max_groups;
     int warm_start;                // lambda holds an initial guess on entry
+    double *eta_hist;              // optional
 };
 // One launch of the streaming PCG on a shard of block rows (see gato_pcg_stream.hip).
 struct StreamStep {
@@ -201,6 +203,7 @@ struct StreamStep {
     double exit_tol;
     int *done;
     int *iters;
+    double *eta_hist;       // optional history buffer (see PcgLaunch)
 };
 template <typename T, int S> int stream_grid(int K, int max_groups);
 template <typename T, int S> int launch_stream_step(int phase, const StreamStep &a, int grid, hipStream_t st);
@@ -208,7 +211,7 @@ template <typename T, int S>
 int launch_stream_pack(const void *slots, int nslots, const void *y, int K, void *send, hipStream_t st);
 template <typename T, int S>
 int launch_stream_finish(const void *part, int n, int stride, double exit_tol, int last_it, int *done, int *iters,
-                         double *final_eta, hipStream_t st);
+                         double *final_eta, double *eta_hist, hipStream_t st);
 
 template <typename T, int S>
 int launch_pcg_streaming(const Dims &d, const T *Sbd, const T *Pbd, const T *gamma, T *lambda,
@@ -234,7 +237,7 @@ struct Ops {
     int (*stream_grid)(int, int);
     int (*stream_step)(int, const StreamStep &, int, hipStream_t);
     int (*stream_pack)(const void *, int, const void *, int, void *, hipStream_t);
-    int (*stream_finish)(const void *, int, int, double, int, int *, int *, double *, hipStream_t);
+    int (*stream_finish)(const void *, int, int, double, int, int *, int *, double *, double *, hipStream_t);
 };
 const Ops *find_ops(int S, int C, int dtype);
 

@@ -209,6 +209,8 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
 
     T gamma_ = (T)0, delta = (T)0, alpha = (T)0, beta = (T)0, gamma_new = (T)0;
     products(gamma_, delta);
+    const bool rec = a.eta_hist && wg == 0 && tid == 0 && sys == 0;
+    if (rec) a.eta_hist[0] = (double)gamma_;
     int iters = a.max_iters;
     const T tol = (T)a.exit_tol;
     if (!aborted) {
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
             __syncthreads();
             products(gamma_new, delta);
             if (aborted) break;
+            if (rec) a.eta_hist[it + 1] = (double)gamma_new;
             if (fabs(gamma_new) < tol) { iters = it; break; }               // gato_pcg.cuh:404-411
             beta = gamma_new / gamma_;
             alpha = gamma_new / (delta - beta * gamma_new / alpha);

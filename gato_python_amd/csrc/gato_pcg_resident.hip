@@ -306,6 +306,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     }
     rt = pinv_times(&xs[1][j * SP]);
     allreduce_and_halo(rt, r * rt, eta);
+    const bool rec = a.eta_hist && wg == 0 && tid == 0 && sys == 0;
+    if (rec) a.eta_hist[0] = (double)eta;
     if (!aborted) {
         p = rt;
         if (active) xs[0][(j + 1) * SP + r_] = p;
@@ -340,6 +342,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             allreduce_and_halo(rt, r * rt, eta_new);
             GATO_STAMP(4)
             if (aborted) break;
+            if (rec) a.eta_hist[it + 1] = (double)eta_new;
             if (fabs(eta_new) < tol) { iters = it; break; }                     // :404-411
             const T beta = eta_new / eta;                                       // :415
             p = rt + beta * p;                                                  // :416-419
@@ -448,6 +451,8 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
     __syncthreads();
     f32x2 rt = times_window(pm, &xs[1][j * SP]);                          // gato_pcg.cuh:316-335
     float eta = block_sum(r[0] * rt[0] + r[1] * rt[1]), eta_new = 0.f;
+    const bool rec = a.eta_hist && tid == 0 && sys == 0;
+    if (rec) a.eta_hist[0] = (double)eta;
     f32x2 p = rt, ups;
     put(xs[0], p);
     __syncthreads();
@@ -463,6 +468,7 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         __syncthreads();
         rt = times_window(pm, &xs[1][j * SP]);
         eta_new = block_sum(r[0] * rt[0] + r[1] * rt[1]);
+        if (rec) a.eta_hist[it + 1] = (double)eta_new;
         if (fabsf(eta_new) < tol) { iters = it; break; }                   // :404-411
         const float beta = eta_new / eta;
         p = rt + beta * p;

@@ -111,6 +111,7 @@ __global__ __launch_bounds__((StreamCfg<T, S>::THREADS)) void stream_step_kernel
         const T eta = slot_sum<T, THREADS>((const T *)a.part_num, a.num_n, a.num_stride, red);
         const T v = slot_sum<T, THREADS>((const T *)a.part_den, a.den_n, a.den_stride, red);
         coef = eta / v;                                                                   // alpha
+        if (a.eta_hist && blockIdx.x == 0 && tid == 0) a.eta_hist[a.it] = (double)eta;    // eta after iteration it-1 (init: 0)
     } else if (blockIdx.x == 0 && tid == 0) {
         *a.done = 0;
         *a.iters = a.max_iters;
@@ -258,13 +259,14 @@ __global__ __launch_bounds__((StreamCfg<T, S>::THREADS)) void stream_step_kernel
 // After the last iteration: evaluate the exit test of iteration max_iters-1.
 template <typename T, int THREADS>
 __global__ __launch_bounds__(THREADS) void stream_finish_kernel(const T *part, int n, int stride, T exit_tol, int last_it,
-                                                                int *done, int *iters, double *final_eta)
+                                                                int *done, int *iters, double *final_eta, double *eta_hist)
 {
     __shared__ T red[THREADS / 64];
     if (*done) return;
     const T eta_new = slot_sum<T, THREADS>(part, n, stride, red);
     if (threadIdx.x == 0) {
         if (final_eta) *final_eta = (double)eta_new;
+        if (eta_hist && last_it >= 0) eta_hist[last_it + 1] = (double)eta_new;
         if (last_it >= 0 && fabs(eta_new) < exit_tol) { *done = 1; *iters = last_it; }
     }
 }
@@ -326,10 +328,10 @@ int launch_stream_pack(const void *slots, int nslots, const void *y, int K, void
 
 template <typename T, int S>
 int launch_stream_finish(const void *part, int n, int stride, double exit_tol, int last_it, int *done, int *iters,
-                         double *final_eta, hipStream_t st)
+                         double *final_eta, double *eta_hist, hipStream_t st)
 {
     hipLaunchKernelGGL((stream_finish_kernel<T, 256>), dim3(1), dim3(256), 0, st, (const T *)part, n, stride, (T)exit_tol,
-                       last_it, done, iters, final_eta);
+                       last_it, done, iters, final_eta, eta_hist);
     GATO_HIP_CHECK(hipGetLastError());
     return GATO_OK;
 }
@@ -356,6 +358,7 @@ int launch_pcg_streaming(const Dims &d, const T *Sbd, const T *Pbd, const T *gam
     memset(&a, 0, sizeof(a));
     a.K = K; a.max_iters = max_iters; a.exit_tol = (double)exit_tol; a.done = w.done; a.iters = iters;
     a.first_global = a.last_global = 1;
+    a.eta_hist = w.eta_hist;
     a.num_n = a.den_n = grid; a.num_stride = a.den_stride = 1;
     int rc;
     if (warm) {
@@ -382,7 +385,7 @@ int launch_pcg_streaming(const Dims &d, const T *Sbd, const T *Pbd, const T *gam
         if ((rc = launch_stream_step<T, S>(2, a, grid, st))) return rc;
     }
     return launch_stream_finish<T, S>(pb(max_iters), grid, 1, (double)exit_tol, max_iters - 1, w.done, iters,
-                                      (double *)w.scalars, st);
+                                      (double *)w.scalars, w.eta_hist, st);
 }
 
 #define X(S_, C_)                                                                                                  \
@@ -396,8 +399,8 @@ int launch_pcg_streaming(const Dims &d, const T *Sbd, const T *Pbd, const T *gam
     template int launch_stream_step<double, S_>(int, const StreamStep &, int, hipStream_t);                         \
     template int launch_stream_pack<float, S_>(const void *, int, const void *, int, void *, hipStream_t);          \
     template int launch_stream_pack<double, S_>(const void *, int, const void *, int, void *, hipStream_t);         \
-    template int launch_stream_finish<float, S_>(const void *, int, int, double, int, int *, int *, double *, hipStream_t); \
-    template int launch_stream_finish<double, S_>(const void *, int, int, double, int, int *, int *, double *, hipStream_t);
+    template int launch_stream_finish<float, S_>(const void *, int, int, double, int, int *, int *, double *, double *, hipStream_t); \
+    template int launch_stream_finish<double, S_>(const void *, int, int, double, int, int *, int *, double *, double *, hipStream_t);
 GATO_SHAPES(X)
 #undef X
 

@@ -155,6 +155,17 @@ class Solver:
         _lib.check(_lib.lib().gato_pcg_last_ms(self._h, ct.byref(ms)))
         return ms.value
 
+    def eta_history(self, n: int):
+        """eta = r . Pinv r after the initial step and after each of the first n iterations (needs record_eta=1)."""
+        ptr = int(_lib.lib().gato_solver_buffer(self._h, 10))
+        buf = (ct.c_double * (n + 1))()
+        hip = ct.CDLL("libamdhip64.so")
+        torch.cuda.synchronize(self.device)
+        rc = hip.hipMemcpy(buf, ct.c_void_p(ptr), 8 * (n + 1), 2)
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy failed: {rc}")
+        return np.frombuffer(buf, dtype=np.float64).copy()
+
     def check_status(self):
         _lib.check(_lib.lib().gato_pcg_status(self._h, None))
 

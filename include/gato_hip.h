@@ -67,7 +67,9 @@ int gato_solver_create(int S, int C, int K, int dtype, int device, gato_solver *
 int gato_solver_create_batched(int S, int C, int K, int B, int dtype, int device, gato_solver **out);
 int gato_solver_destroy(gato_solver *s);
 /* Workspace device pointers (valid for the solver's lifetime), for stage-level tests:
- * which: 0 G_dense, 1 C_dense, 2 Ginv_dense, 3 S, 4 Pinv, 5 gamma, 6 lambda, 7 dz, 8 iters(int) */
+ * which: 0 G_dense, 1 C_dense, 2 Ginv_dense, 3 S, 4 Pinv, 5 gamma, 6 lambda, 7 dz, 8 iters(int),
+ * 10 eta history (double[max_iters+1]: eta = r.Pinv r after the initial step and after every iteration; filled when
+ * option record_eta = 1 and max_iters <= 4096 - the reference only prints it under DEBUG_MODE, gato_pcg.cuh:397-400) */
 void *gato_solver_buffer(gato_solver *s, int which);
 /* Options: pcg_mode (GATO_PCG_*), pcg_threads (0 = auto; threads per workgroup of the resident
  * kernel), pcg_groups (0 = auto; workgroups of the resident kernel), true_warm_start (0 = the

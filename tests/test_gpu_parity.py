@@ -464,3 +464,25 @@ def test_other_compiled_shapes(S, C, K, dt):
     lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
     assert rel(host(lam), lam_o) < (1e-8 if f64 else 5e-3) and rel(host(dz), dz_o) < (1e-8 if f64 else 5e-3)
     sol.close()
+
+
+@pytest.mark.parametrize("opts", [{}, dict(no_single_lds=1), dict(pcg_mode=_lib.PCG_STREAMING), dict(pcg_variant=1)])
+def test_eta_history(opts):
+    """record_eta: the residual measure eta = r.Pinv r per iteration (what the reference prints under DEBUG_MODE,
+    gato_pcg.cuh:397-400) equals the oracle's history."""
+    S, C, K = 14, 7, 50
+    s = synth.make_system(S, C, K, seed=3)
+    out = o.linsys_solve(*s.csr_args(), S, C, K, 1e-9, 200, s.rho, dtype=np.float64, return_all=True)
+    sol = make_solver(S, C, K, np.float64)
+    sol.set_option("record_eta", 1)
+    for k, v in opts.items():
+        sol.set_option(k, v)
+    lam, it = sol.pcg(sol.to_device(out["S"]), sol.to_device(out["Pinv"]), sol.to_device(out["gamma"]), 1e-9, 200)
+    n = int(host(it)[0])
+    hist = sol.eta_history(n + 1)
+    ref = np.asarray(out["eta"])
+    assert abs(n - out["iters"]) <= (2 if opts.get("pcg_variant") else 0)
+    m = min(len(ref), len(hist)) - 1
+    tol = 1e-5 if opts.get("pcg_variant") else 1e-8
+    assert np.allclose(hist[:m], ref[:m], rtol=tol, atol=1e-12), (hist[:5], ref[:5])
+    sol.close()
