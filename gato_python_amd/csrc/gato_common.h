@@ -41,17 +41,20 @@ __device__ __forceinline__ double fmaT(double a, double b, double c) { return __
 // gfx9 row broadcasts; the total lands in lane 63 and is returned wave-uniform.  Fixed order, so the
 // result is bitwise reproducible.  (A __shfl_xor butterfly compiles to six dependent ds_bpermute_b32,
 // each an LDS-crossbar round trip.)
-template <int CTRL, int ROW_MASK>
+// FULL = every lane has a valid source and all rows take part (quad permutes, mirrors): the move is issued with
+// bound_ctrl, which makes the `old` operand dead so that the compiler does not zero a register pair before every
+// DPP move (matters for f64, which has no DPP add: 8 v_mov less per wave sum).  The row broadcasts keep old = 0.
+template <int CTRL, int ROW_MASK, bool FULL>
 __device__ __forceinline__ float dpp_mov(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, FULL));
 }
-template <int CTRL, int ROW_MASK>
+template <int CTRL, int ROW_MASK, bool FULL>
 __device__ __forceinline__ double dpp_mov(double v)
 {
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, FULL);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, FULL);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ float lane63(float v)
@@ -68,12 +71,12 @@ __device__ __forceinline__ double lane63(double v)
 template <typename T>
 __device__ __forceinline__ T wave_sum_dpp(T v)
 {
-    v += dpp_mov<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141, 0xf>(v);   // row_half_mirror
-    v += dpp_mov<0x140, 0xf>(v);   // row_mirror      -> every lane holds its row's sum
-    v += dpp_mov<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
-    v += dpp_mov<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
+    v += dpp_mov<0xB1, 0xf, true>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf, true>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf, true>(v);   // row_half_mirror
+    v += dpp_mov<0x140, 0xf, true>(v);   // row_mirror      -> every lane holds its row's sum
+    v += dpp_mov<0x142, 0xa, false>(v);  // row_bcast:15 into rows 1,3
+    v += dpp_mov<0x143, 0xc, false>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
     return lane63(v);
 }
 

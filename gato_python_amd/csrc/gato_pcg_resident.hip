@@ -178,7 +178,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // One reduction + halo exchange.  `val` = the vector just produced (upsilon or r~), `prod` the
     // lane's dot contribution.  On return: total in every thread; gh[][] = neighbours' boundary
     // blocks of `val` (zeros where there is no neighbour).
-    const int abl = a.ablate;     // diagnostic timing-only switches (results are garbage when set)
+    const int abl = STAMP ? a.ablate : 0;   // diagnostic timing-only switches, compiled out of the production build
     auto allreduce_and_halo = [&](T val, T prod, T &total) {
         ++epoch;
         if (abl & 4) { total = (T)1 + prod * (T)1e-30; return; }
@@ -306,8 +306,9 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     }
     rt = pinv_times(&xs[1][j * SP]);
     allreduce_and_halo(rt, r * rt, eta);
-    const bool rec = a.eta_hist && wg == 0 && tid == 0 && sys == 0;
-    if (rec) a.eta_hist[0] = (double)eta;
+    const bool rec_on = a.eta_hist != nullptr;                 // wave-uniform: one scalar branch when recording is off
+    const bool rec = wg == 0 && tid == 0 && sys == 0;
+    if (rec_on && rec) a.eta_hist[0] = (double)eta;
     if (!aborted) {
         p = rt;
         if (active) xs[0][(j + 1) * SP + r_] = p;
@@ -342,7 +343,9 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             allreduce_and_halo(rt, r * rt, eta_new);
             GATO_STAMP(4)
             if (aborted) break;
-            if (rec) a.eta_hist[it + 1] = (double)eta_new;
+            if (rec_on) {
+                if (rec) a.eta_hist[it + 1] = (double)eta_new;
+            }
             if (fabs(eta_new) < tol) { iters = it; break; }                     // :404-411
             const T beta = eta_new / eta;                                       // :415
             p = rt + beta * p;                                                  // :416-419
