@@ -39,8 +39,13 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const bool batched = a.batch > 1;
-    const int W = batched ? 1 : (int)gridDim.x;
-    const int wg = batched ? 0 : (int)blockIdx.x;
+    // xcd_pack: see pcg_resident_kernel (placement hint: the working groups share X XCDs)
+    const int X = a.xcd_pack;
+    if (X > 0 && (int)(blockIdx.x & 7) >= X) return;
+    const int per_x = X > 0 ? (int)(gridDim.x >> 3) : 0;
+    const int wg = batched ? 0 : (X > 0 ? (int)(blockIdx.x & 7) * per_x + (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+    const int W = batched ? 1 : (X > 0 ? a.groups : (int)gridDim.x);
+    if (X > 0 && wg >= W) return;
     const size_t sys = batched ? blockIdx.x : 0;
     const int K = a.K;
     const int k0 = wg * a.knots_per_wg;
@@ -279,7 +284,8 @@ int launch_pcg_cg1(const PcgLaunch &a, hipStream_t st)
         }
     }
     if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-    hipLaunchKernelGGL((pcg_cg1_kernel<T, S, MAXT>), dim3(a.batch > 1 ? a.batch : a.groups), dim3(a.threads), 0, st, a);
+    const int nblocks = a.batch > 1 ? a.batch : (a.xcd_pack > 0 ? 8 * ((a.groups + a.xcd_pack - 1) / a.xcd_pack) : a.groups);
+    hipLaunchKernelGGL((pcg_cg1_kernel<T, S, MAXT>), dim3(nblocks), dim3(a.threads), 0, st, a);
     GATO_HIP_CHECK(hipGetLastError());
     if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
     return GATO_OK;

@@ -76,7 +76,9 @@ void *gato_solver_buffer(gato_solver *s, int which);
  * reference's behaviour: lambda restarts from zero, gato_pcg.cuh:303; 1 = d_lambda of gato_pcg /
  * gato_linsys_device is read as the initial guess, r0 = gamma - S lambda0), pcg_variant (0 = the reference's PCG
  * recurrence; 1 = opt-in single-reduction Chronopoulos-Gear recurrence of the resident kernel: one inter-workgroup
- * hand-off per iteration instead of two, same solution to solver tolerance, different rounding), time_pcg (record
+ * hand-off per iteration instead of two, same solution to solver tolerance, different rounding), xcd_pack (-1 auto:
+ * launches of up to 32 workgroups are placed on one XCD - a placement hint, never needed for correctness; 0 off),
+ * time_pcg (record
  * hipEvents around the PCG launch), no_single_lds / stamp_pcg / ablate (diagnostics). */
 int gato_solver_set_option(gato_solver *s, const char *name, int value);
 int gato_solver_get_option(gato_solver *s, const char *name, int *value);
