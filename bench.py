@@ -164,7 +164,13 @@ def cpu_baseline(sysm, dt, budget_s=10.0):
     from oracle import c_oracle as co
     S, C, K = sysm.S, sysm.C, sysm.K
     best = None
-    for threads in sorted({1, min(co.max_threads(), os.cpu_count() or 1)}):
+    # thread counts tried: 1 and the box's CPU share (the GPU boxes expose all host cores but grant ~16 per GPU;
+    # oversubscribing the OpenMP loops beyond that only slows them down)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    for threads in sorted({1, min(co.max_threads(), avail, 16)}):
         co.set_threads(threads)
         co.linsys_solve(*sysm.csr_args(), S, C, K, 0.0, MAX_ITERS, sysm.rho, dtype=dt)   # warm-up
         n, t0 = 0, time.perf_counter()
@@ -244,6 +250,10 @@ def main():
                 r = r2
             r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
             r["hbm_bytes_per_launch_pmc"] = committed_traffic(other)
+            if not args.no_cpu:
+                So, Co, Ko, dto, _ = WORKLOADS[other]
+                from gato_python_amd import synth as _synth
+                r["cpu_baseline"] = cpu_baseline(_synth.make_system(So, Co, Ko, seed=0), dto, budget_s=3.0)
             sweep.append(r)
         # opt-in single-reduction variant (one hand-off per iteration; rounding differs from the reference recurrence)
         for other in ("iiwa_14_7_k512_f32", "iiwa_14_7_k4096_f32", "s32_c16_k1024_f32"):
