@@ -143,6 +143,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
             unsigned long long raw[PM][2 * GPV], hraw[2][GPV];
             const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
             bool fail = false;
+            if (W > 32) __builtin_amdgcn_s_sleep(10);   // see the same line in gato_pcg_resident.hip: -6..-17 % here
             for (unsigned spin = 0;; ++spin) {
 #pragma unroll
                 for (int m = 0; m < PM; ++m)

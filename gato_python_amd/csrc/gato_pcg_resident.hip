@@ -226,6 +226,10 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 unsigned long long raw[Cfg::PM][GPV], hraw[GPV];
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 bool fail = false;
+                // Cross-XCD launches: the first poll can never hit (the publishers' stores need a fabric round
+                // trip), and W*W early loads only queue in front of those stores.  ~0.35 us of sleep before the
+                // first poll measured -5..-10 % per iteration for W > 32 and +6 % for one-XCD launches.
+                if (W > 32) __builtin_amdgcn_s_sleep(12);
                 for (unsigned spin = 0;; ++spin) {
 #pragma unroll
                     for (int m = 0; m < Cfg::PM; ++m) {
