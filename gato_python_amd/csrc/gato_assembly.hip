@@ -135,7 +135,7 @@ __device__ __forceinline__ void mm(T *out, const T *A, const T *B, int lane)
         const int r = e % m, c = e / m;
         T res = (T)0;
 #pragma unroll
-        for (int t = 0; t < k; ++t) res += A[t * m + r] * (TB ? B[t * n + c] : B[c * k + t]);
+        for (int t = 0; t < k; ++t) res = gato::fmaT(A[t * m + r], TB ? B[t * n + c] : B[c * k + t], res);
         out[e] = res;
     }
 }
@@ -146,7 +146,7 @@ __device__ __forceinline__ void mv(T *out, const T *A, const T *x, int lane)
     for (int r = lane; r < m; r += WAVE) {
         T res = (T)0;
 #pragma unroll
-        for (int c = 0; c < n; ++c) res += A[r + c * m] * x[c];
+        for (int c = 0; c < n; ++c) res = gato::fmaT(A[r + c * m], x[c], res);   // explicit: every kernel contracts alike
         out[r] = res;
     }
 }
@@ -157,7 +157,7 @@ __device__ __forceinline__ void mTv(T *out, const T *A, const T *x, int lane)
     for (int i = lane; i < n; i += WAVE) {
         T res = (T)0;
 #pragma unroll
-        for (int t = 0; t < m; ++t) res += A[i * m + t] * x[t];
+        for (int t = 0; t < m; ++t) res = gato::fmaT(A[i * m + t], x[t], res);
         out[i] = res;
     }
 }
@@ -401,6 +401,280 @@ __global__ __launch_bounds__(WAVE) void ss_kernel(const T *__restrict__ Sbd, T *
     }
 }
 
+// ---- A1 + A2 + A3 in ONE launch ------------------------------------------------------------------------------
+// A small solve is bound by dependent launches, not by work: memset, scatter, inversions, Schur and stair were five
+// launches of ~5 us each in front of a PCG loop of ~230 us (IIWA 14/7/50, profiles/).  Here the workgroup of knot k
+// produces everything the stage kernels write for knot k PLUS the two stair blocks that couple knots k-1 and k
+// (Pinv[k].left, Pinv[k-1].right).  Those need theta_{k-1}^-1, which the workgroup RECOMPUTES from knot k-2's blocks
+// instead of waiting for its neighbour: twice the arithmetic, no inter-workgroup hand-off (a flag hand-off across
+// XCDs measured 5-8 us here, more than the whole recomputation), no co-residency requirement, any K.
+//  1. gather the CSR entries of knots k-2..k (rows are contiguous, so the entries are one contiguous index range:
+//     a thread per ENTRY, row found by bisection of the row pointers held in LDS - two dependent global loads deep,
+//     coalesced) into dense LDS blocks; knot k's blocks are written out once (no memset);
+//  2. invert Q_{k-2}, R_{k-2}, Q_{k-1}, R_{k-1}, Q_k, R_k on six wavefronts at the same time (register Gauss-Jordan);
+//  3. phi/theta of knots k-1 and k with the MFMA tiles spread over the waves; gamma, S[k], Pinv[k].main;
+//  4. the two stair blocks.
+// Per block the instruction sequence is that of invert_G_kernel / schur_kernel / ss_kernel: results are bit-identical
+// (tests/test_gpu_parity.py::test_fused_assembly_is_bit_identical_to_the_stage_kernels).
+template <int NT, typename T>
+__device__ __forceinline__ void copy_nt(T *dst, const T *__restrict__ src, int n, int tid)
+{
+    for (int i = tid; i < n; i += NT) dst[i] = src[i];
+}
+
+// MFMA tiles of an M x N result spread over the workgroup's waves: tile t runs on wave (first + t) % NW
+template <typename T, int M, int N, int NW, typename TileFn, typename StoreFn>
+__device__ __forceinline__ void mfma_tiles_on_waves(int wave, int lane, int first, TileFn tile, StoreFn store)
+{
+    constexpr int NTN = (N + 15) / 16;
+#pragma unroll
+    for (int mt = 0; mt < (M + 15) / 16; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) {
+            if ((first + mt * NTN + nt) % NW != wave) continue;                 // wave-uniform
+            typename Mfma<T>::acc_t acc = {0, 0, 0, 0};
+            acc = tile(mt, nt, acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = mt * 16 + Mfma<T>::row(lane, j), c = nt * 16 + (lane & 15);
+                if (r < M && c < N) store(r, c, acc[j]);
+            }
+        }
+    }
+}
+
+template <typename T, int S, int C>
+struct AsmLds {                                   // element offsets into the dynamic LDS block
+    static constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C;
+    static constexpr int Q = 0;                   // 3 x SS   Q_{k-2}, Q_{k-1}, Q_k: raw, then inverted in place
+    static constexpr int R = Q + 3 * SS;          // 3 x CC
+    static constexpr int AB = R + 3 * CC;         // 2 x (SS + SC)   [A | B] of block rows k-2, k-1
+    static constexpr int PHI = AB + 2 * (SS + SC);   // 2 x SS  phi of knots k-1, k
+    static constexpr int BR = PHI + 2 * SS;       // 2 x SC
+    static constexpr int TH = BR + 2 * SC;        // 2 x SS   theta, then -theta^-1 in place (Pinv main of knots k-1, k)
+    static constexpr int TT = TH + 2 * SS;        // 2 x SS   stair temporaries
+    static constexpr int VQ = TT + 2 * SS;        // q_{k-1}, r_{k-1}, q_k
+    static constexpr int VV = VQ + 2 * S + C;     // 3 x S
+    static constexpr int ELEMS = (VV + 3 * S + 3) / 4 * 4;
+    static constexpr int PTR_G = 3 * n + 1, PTR_C = 2 * S + 1;
+    static constexpr size_t BYTES = sizeof(T) * ELEMS + sizeof(int) * (PTR_G + PTR_C);
+};
+
+// largest i in [0, nrows) with ptr[i] <= e  (ptr[0] <= e < ptr[nrows])
+__device__ __forceinline__ int row_of_entry(const int *ptr, int nrows, int e)
+{
+    int lo = 0, hi = nrows;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <typename T, int S, int C, int NT>
+__global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStride bs)
+{
+    typedef AsmLds<T, S, C> L;
+    constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C, NW = NT / WAVE, ABS = SS + SC;
+    static_assert(NW >= 6, "six inversions run side by side");
+    constexpr int TILES = ((S + 15) / 16) * ((S + 15) / 16);
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T *lds = (T *)lds_raw;
+    T *sQ = lds + L::Q, *sR = lds + L::R, *sAB = lds + L::AB, *sPhi = lds + L::PHI, *sBR = lds + L::BR;
+    T *sTh = lds + L::TH, *sT = lds + L::TT, *sq = lds + L::VQ, *sv = lds + L::VV;
+    int *sPtrG = (int *)(lds + L::ELEMS), *sPtrC = sPtrG + L::PTR_G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sys = blockIdx.y;
+    const T *g = (const T *)a.g + sys * bs.n, *c = (const T *)a.c + sys * bs.sk;
+    T *Gd = (T *)a.Gd + sys * bs.g, *Cd = (T *)a.Cd + sys * bs.c, *Ginv = (T *)a.Ginv + sys * bs.g;
+    T *Sbd = (T *)a.Sbd + sys * bs.bd, *Pbd = (T *)a.Pbd + sys * bs.bd, *gamma = (T *)a.gamma + sys * bs.sk;
+    const T rho = (T)a.rho;
+    // this knot's operands (sub-knot 1) and the previous knot's (sub-knot 0)
+    T *sQk = sQ + 2 * SS, *sRk = sR + 2 * CC, *sQm = sQ + SS, *sRm = sR + CC, *sQmm = sQ, *sRmm = sR;
+    T *sA1 = sAB + ABS, *sB1 = sA1 + SS, *sA0 = sAB, *sB0 = sAB + SS;
+    T *sPhi1 = sPhi + SS, *sPhi0 = sPhi, *sBR1 = sBR + SC, *sBR0 = sBR, *sTh1 = sTh + SS, *sTh0 = sTh;
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (a.stamps && blockIdx.x == (K > 2 ? 2 : 0) && sys == 0 && tid == 0) a.stamps[n_stamp++] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp();
+
+    for (int k = blockIdx.x; k < K; k += gridDim.x) {
+        const bool first = k == 0, last = k == K - 1;
+        const bool full0 = k >= 2;                                           // theta_{k-1} is a Schur block (k-1 >= 1)
+        const size_t gk = (size_t)k * (SS + CC);
+        const size_t cm = first ? 0 : (size_t)(k - 1) * ABS;
+        T *Sk = Sbd + (size_t)k * 3 * SS, *Pk = Pbd + (size_t)k * 3 * SS;
+        __syncthreads();
+        // ---- 1. blocks of knots k-2 .. k into LDS ----
+        if (a.mode == 0) {
+            const T *G_val = (const T *)a.G_val + sys * bs.nnzG, *C_val = (const T *)a.C_val + sys * bs.nnzC;
+            const int r0 = (k >= 2 ? k - 2 : 0) * n, nrG = k * n + (last ? S : n) - r0;
+            const int c0 = (k >= 2 ? k - 1 : 1) * S, nrC = first ? 0 : (k + 1) * S - c0;
+            for (int i = tid; i <= nrG; i += NT) sPtrG[i] = a.G_row[r0 + i];
+            if (nrC) for (int i = tid; i <= nrC; i += NT) sPtrC[i] = a.C_row[c0 + i];
+            for (int i = tid; i < 3 * SS + 3 * CC + 2 * ABS; i += NT) lds[i] = (T)0;   // sQ, sR, sAB are contiguous
+            __syncthreads();
+            const int eG0 = sPtrG[0], nG = sPtrG[nrG] - eG0;
+            const int eC0 = nrC ? sPtrC[0] : 0, nC = nrC ? sPtrC[nrC] - eC0 : 0;
+            // U entries per thread and round: all 2U loads are in flight before the first bisection result is needed
+            constexpr int U = 4;
+            for (int t0 = tid; t0 < nG + nC; t0 += NT * U) {
+                int col[U];
+                T val[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int t = t0 + u * NT;
+                    if (t < nG) { col[u] = a.G_col[eG0 + t]; val[u] = G_val[eG0 + t]; }
+                    else if (t < nG + nC) { col[u] = a.C_col[eC0 + (t - nG)]; val[u] = C_val[eC0 + (t - nG)]; }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int t = t0 + u * NT;
+                    if (t < nG) {                                          // csr_to_custom_G, gato_schur.cuh:674-704
+                        const int row = r0 + row_of_entry(sPtrG, nrG, eG0 + t);
+                        const int knot = row / n, isr = row - knot * n, qi = knot - (k - 2);
+                        const int isc = col[u] % n;
+                        const T v = val[u] + (col[u] == row ? rho : (T)0);
+                        if (isc < S) { if (isr < S) sQ[qi * SS + isc * S + isr] = v; }
+                        else if (isr >= S) sR[qi * CC + (isc - S) * C + (isr - S)] = v;
+                    } else if (t < nG + nC) {                              // csr_to_custom_C, :707-743
+                        const int row = c0 + row_of_entry(sPtrC, nrC, eC0 + (t - nG));
+                        const int br = row / S - 1, i = row - (br + 1) * S;
+                        if (col[u] / n <= br) sAB[(br - (k - 2)) * ABS + (col[u] % n) * S + i] = val[u];
+                    }
+                }
+            }
+        } else {
+            const T *Gin = a.mode == 2 ? (const T *)a.G_val + sys * bs.g : Gd;
+            const T r2 = a.mode == 2 ? rho : (T)0;
+#pragma unroll
+            for (int qi = 0; qi < 3; ++qi) {
+                const int knot = k - 2 + qi;
+                if (knot < 0) continue;
+                const size_t go = (size_t)knot * (SS + CC);
+                for (int i = tid; i < SS; i += NT) sQ[qi * SS + i] = Gin[go + i] + ((i % (S + 1) == 0) ? r2 : (T)0);
+                if (knot < K - 1)
+                    for (int i = tid; i < CC; i += NT) sR[qi * CC + i] = Gin[go + SS + i] + ((i % (C + 1) == 0) ? r2 : (T)0);
+                if (qi < 2 && knot < K - 1) copy_nt<NT>(sAB + qi * ABS, Cd + (size_t)knot * ABS, ABS, tid);
+            }
+        }
+        if (first) { for (int i = tid; i < S; i += NT) sq[i] = g[i]; }
+        else {
+            copy_nt<NT>(sq, g + (size_t)(k - 1) * n, n, tid);                // q_{k-1}, r_{k-1}
+            for (int i = tid; i < S; i += NT) sq[n + i] = g[(size_t)k * n + i];   // q_k
+        }
+        __syncthreads();
+        stamp();                                                             // 1: gathered
+        if (a.mode != 1) {                                                   // knot k's dense blocks, written once
+            for (int i = tid; i < SS; i += NT) Gd[gk + i] = sQk[i];
+            if (!last) for (int i = tid; i < CC; i += NT) Gd[gk + SS + i] = sRk[i];
+            if (a.mode == 0 && !first) for (int i = tid; i < ABS; i += NT) Cd[cm + i] = sA1[i];
+        }
+        if (first) for (int i = tid; i < SS; i += NT) Pk[SS + i] = -sQk[i];  // Pinv[0].main = -Q_0   :75-81
+        if (k == 1) for (int i = tid; i < SS; i += NT) sTh0[i] = -sQm[i];    // ... which is this knot's left neighbour
+        __syncthreads();
+        // ---- 2. six inversions side by side, in place ----
+        if (wave == 0) invert_to<T, S>(sQk, sQk, lane, (T)1);
+        else if (wave == 1) { if (!first) invert_to<T, S>(sQm, sQm, lane, (T)1); }
+        else if (wave == 2) { if (!first) invert_to<T, C>(sRm, sRm, lane, (T)1); }
+        else if (wave == 3) { if (full0) invert_to<T, S>(sQmm, sQmm, lane, (T)1); }
+        else if (wave == 4) { if (full0) invert_to<T, C>(sRmm, sRmm, lane, (T)1); }
+        else if (wave == 5) { if (!last) invert_to<T, C>(sRk, sRk, lane, (T)1); }
+        __syncthreads();
+        stamp();                                                             // 2: inverted
+        for (int i = tid; i < SS; i += NT) Ginv[gk + i] = sQk[i];
+        if (!last) for (int i = tid; i < CC; i += NT) Ginv[gk + SS + i] = sRk[i];
+        if (first) {                                                         // :26-147
+            if (wave == 0) mv<T, S, S>(sv, sQk, sq, lane);
+            for (int i = tid; i < SS; i += NT) {
+                Sk[i] = (T)0;                                                // S[0].left: unused (:157-165)
+                Sk[SS + i] = -sQk[i];                                        // :120-126
+                Pk[i] = (T)0;
+                if (last) { Pk[2 * SS + i] = (T)0; Sk[2 * SS + i] = (T)0; }
+            }
+            __syncthreads();
+            for (int i = tid; i < S; i += NT) gamma[i] = c[i] - sv[i];       // :131-146, + c_0 (D4)
+            continue;
+        }
+        // ---- 3. Schur blocks of knot k, theta of knot k-1 ----
+        // phi = A Q^-1 (:277-285), BR = B R^-1 (:293-301)
+        mfma_tiles_on_waves<T, S, S, NW>(wave, lane, 0,
+            [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sA1, sQm, mt, nt, lane, acc); },
+            [&](int r, int cc, T v) {
+                sPhi1[cc * S + r] = v;
+                Sk[cc * S + r] = -v;                                         // S[k].left = -phi      :388-394
+                Sk[2 * SS - 3 * SS + r * S + cc] = -v;                       // S[k-1].right = -phi^T :443-455
+            });
+        mfma_tiles_on_waves<T, S, C, NW>(wave, lane, TILES,
+            [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, C, C, false>(sB1, sRm, mt, nt, lane, acc); },
+            [&](int r, int cc, T v) { sBR1[cc * S + r] = v; });
+        if (full0) {
+            mfma_tiles_on_waves<T, S, S, NW>(wave, lane, 2 * TILES,
+                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sA0, sQmm, mt, nt, lane, acc); },
+                [&](int r, int cc, T v) { sPhi0[cc * S + r] = v; });
+            mfma_tiles_on_waves<T, S, C, NW>(wave, lane, 3 * TILES,
+                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, C, C, false>(sB0, sRmm, mt, nt, lane, acc); },
+                [&](int r, int cc, T v) { sBR0[cc * S + r] = v; });
+        }
+        if (wave == NW - 1) mv<T, S, S>(sv, sQk, sq + n, lane);              // Q_k^-1 q_k           :306-310
+        __syncthreads();
+        if (wave == NW - 1) mv<T, S, S>(sv + S, sPhi1, sq, lane);            // phi q_{k-1}          :316-320
+        if (wave == NW - 2) mv<T, S, C>(sv + 2 * S, sBR1, sq + S, lane);     // BR r_{k-1}           :324-328
+        // theta = phi A^T + Q^-1 + BR B^T (:342-384)
+        mfma_tiles_on_waves<T, S, S, NW>(wave, lane, 0,
+            [&](int mt, int nt, typename Mfma<T>::acc_t acc) {
+                acc = mfma_tile<T, S, S, S, true>(sPhi1, sA1, mt, nt, lane, acc);
+                return mfma_tile<T, S, C, S, true>(sBR1, sB1, mt, nt, lane, acc);
+            },
+            [&](int r, int cc, T v) {
+                const T th = v + sQk[cc * S + r];
+                sTh1[cc * S + r] = th;
+                Sk[SS + cc * S + r] = -th;                                   // S[k].main   :398-404
+            });
+        if (full0)
+            mfma_tiles_on_waves<T, S, S, NW>(wave, lane, TILES,
+                [&](int mt, int nt, typename Mfma<T>::acc_t acc) {
+                    acc = mfma_tile<T, S, S, S, true>(sPhi0, sA0, mt, nt, lane, acc);
+                    return mfma_tile<T, S, C, S, true>(sBR0, sB0, mt, nt, lane, acc);
+                },
+                [&](int r, int cc, T v) { sTh0[cc * S + r] = v + sQm[cc * S + r]; });
+        __syncthreads();
+        if (wave == 0) invert_to<T, S>(sTh1, sTh1, lane, (T)-1);             // Pinv[k].main = -theta^-1  :407-422
+        else if (wave == 1) { if (full0) invert_to<T, S>(sTh0, sTh0, lane, (T)-1); }
+        else {
+            for (int i = tid - 2 * WAVE; i < S; i += NT - 2 * WAVE) {
+                T gt = sv[i] - c[(size_t)k * S + i];                         // :311-313
+                gt += sv[2 * S + i] + sv[S + i];                             // :336-338
+                gamma[(size_t)k * S + i] = -gt;                              // :435-438
+            }
+            if (last)
+                for (int i = tid - 2 * WAVE; i < SS; i += NT - 2 * WAVE) {
+                    Pk[2 * SS + i] = (T)0;
+                    Sk[2 * SS + i] = (T)0;                                   // last right: unused (:166-174)
+                }
+        }
+        __syncthreads();
+        stamp();                                                             // 3: Schur blocks done
+        for (int i = tid; i < SS; i += NT) Pk[SS + i] = sTh1[i];
+        // ---- 4. symmetric stair between knots k-1 and k (gato_schur.cuh:497-649; S[k].left = -phi) ----
+        mfma_tiles_on_waves<T, S, S, NW>(wave, lane, 0,                      // Pinv[k].main * phi
+            [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sTh1, sPhi1, mt, nt, lane, acc); },
+            [&](int r, int cc, T v) { sT[cc * S + r] = v; });
+        mfma_tiles_on_waves<T, S, S, NW>(wave, lane, TILES,                  // Pinv[k-1].main * phi^T
+            [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, true>(sTh0, sPhi1, mt, nt, lane, acc); },
+            [&](int r, int cc, T v) { sT[SS + cc * S + r] = v; });
+        __syncthreads();
+        mfma_tiles_on_waves<T, S, S, NW>(wave, lane, 0,                      // Pinv[k].left          :578-611
+            [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sT, sTh0, mt, nt, lane, acc); },
+            [&](int r, int cc, T v) { Pk[cc * S + r] = v; });
+        mfma_tiles_on_waves<T, S, S, NW>(wave, lane, TILES,                  // Pinv[k-1].right       :614-648 (D1)
+            [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sT + SS, sTh1, mt, nt, lane, acc); },
+            [&](int r, int cc, T v) { Pk[2 * SS - 3 * SS + cc * S + r] = v; });
+        stamp();                                                             // 4: stair written
+    }
+}
+
 // ---- A9: dz back-substitution (gato_schur.cuh:758-867) -------------------------------------------
 template <typename T, int S, int C>
 __global__ __launch_bounds__(WAVE) void dz_kernel(const T *__restrict__ Ginv, const T *__restrict__ Cd,
@@ -437,14 +711,14 @@ __global__ __launch_bounds__(WAVE) void dz_kernel(const T *__restrict__ Ginv, co
         for (int r = lane; r < S; r += WAVE) {                               // Q_k^-1 (...)         :856-865
             T res = (T)0;
 #pragma unroll
-            for (int cc = 0; cc < S; ++cc) res += sQi[r + cc * S] * st[cc];
+            for (int cc = 0; cc < S; ++cc) res = gato::fmaT(sQi[r + cc * S], st[cc], res);
             dz[(size_t)k * n + r] = res;
         }
         if (!last) {
             for (int r = lane; r < C; r += WAVE) {                           // R_k^-1 (...)         :799-808
                 T res = (T)0;
 #pragma unroll
-                for (int cc = 0; cc < C; ++cc) res += sRi[r + cc * C] * st[S + cc];
+                for (int cc = 0; cc < C; ++cc) res = gato::fmaT(sRi[r + cc * C], st[S + cc], res);
                 dz[(size_t)k * n + S + r] = res;
             }
         }
@@ -503,6 +777,23 @@ int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const
 }
 
 template <typename T, int S, int C>
+int launch_assemble(const Dims &d, const AsmArgs &a, hipStream_t st)
+{
+    constexpr int NT = 512;
+    typedef AsmLds<T, S, C> L;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GATO_HIP_CHECK(hipFuncSetAttribute((const void *)assemble_kernel<T, S, C, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)L::BYTES));
+        attr_set = true;
+    }
+    const int gx = d.K < (1 << 20) ? d.K : (1 << 20);
+    hipLaunchKernelGGL((assemble_kernel<T, S, C, NT>), dim3(gx, d.B), dim3(NT), L::BYTES, st, a, d.K, batch_stride(d));
+    GATO_HIP_CHECK(hipGetLastError());
+    return GATO_OK;
+}
+
+template <typename T, int S, int C>
 int launch_form_ss(const Dims &d, const T *Sbd, T *Pbd, hipStream_t st)
 {
     hipLaunchKernelGGL((ss_kernel<T, S>), dim3(knot_grid(d.K), d.B), dim3(WAVE), 0, st, Sbd, Pbd, d.K, batch_stride(d));
@@ -533,6 +824,8 @@ int launch_compute_dz(const Dims &d, const T *Ginv, const T *Cd, const T *g, con
     template int launch_form_schur<double, S_, C_>(const Dims &, const double *, const double *, const double *, \
                                                    const double *, double *, double *, double *, double *,       \
                                                    hipStream_t);                                                 \
+    template int launch_assemble<float, S_, C_>(const Dims &, const AsmArgs &, hipStream_t);                      \
+    template int launch_assemble<double, S_, C_>(const Dims &, const AsmArgs &, hipStream_t);                     \
     template int launch_form_ss<float, S_, C_>(const Dims &, const float *, float *, hipStream_t);               \
     template int launch_form_ss<double, S_, C_>(const Dims &, const double *, double *, hipStream_t);            \
     template int launch_compute_dz<float, S_, C_>(const Dims &, const float *, const float *, const float *,     \

@@ -38,6 +38,7 @@ static Ops make_ops(int dtype)
         return launch_form_schur<T, S, C>(d, (const T *)Gd, (const T *)Cd, (const T *)g, (const T *)c, (T *)Sb,
                                           (T *)Pb, (T *)gam, (T *)Gi, st);
     };
+    o.assemble = [](const Dims &d, const AsmArgs &a, hipStream_t st) { return launch_assemble<T, S, C>(d, a, st); };
     o.form_ss = [](const Dims &d, const void *Sb, void *Pb, hipStream_t st) {
         return launch_form_ss<T, S, C>(d, (const T *)Sb, (T *)Pb, st);
     };
@@ -126,6 +127,8 @@ struct gato_solver {
         const char *S_full, *P_full, *gamma_full;
     } sh;
     char *ghosts;   // [r|p][ping-pong][left|right][S]
+    int asm_mode;       // option: 0 = auto, 1 = stage kernels one by one (convert / invert / schur / stair), 2 = fused launch
+    int last_asm_fused, stamp_asm;
     double *eta_hist;   // eta after init and after every iteration (option record_eta), GATO_ETA_HIST_MAX + 1 entries
     int record_eta;
 };
@@ -325,6 +328,9 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     if (!strcmp(name, "pcg_mode")) s->pcg_mode = value;
     else if (!strcmp(name, "pcg_threads")) s->pcg_threads = value;
     else if (!strcmp(name, "pcg_groups")) s->pcg_groups = value;
+    else if (!strcmp(name, "asm_mode")) s->asm_mode = value;
+    else if (!strcmp(name, "stamp_asm")) s->stamp_asm = value;
+    else if (!strcmp(name, "stamp_asm")) s->stamp_asm = value;
     else if (!strcmp(name, "stamp_pcg")) s->stamp_pcg = value;
     else if (!strcmp(name, "ablate")) s->ablate = value;
     else if (!strcmp(name, "no_single_lds")) s->no_single_lds = value;
@@ -364,6 +370,8 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "last_mode")) *value = s->last_mode;
     else if (!strcmp(name, "last_pair")) *value = s->plan_pair;
     else if (!strcmp(name, "last_variant")) *value = s->last_variant;
+    else if (!strcmp(name, "asm_mode")) *value = s->asm_mode;
+    else if (!strcmp(name, "last_asm_fused")) *value = s->last_asm_fused;
     else if (!strcmp(name, "num_cus")) *value = s->num_cus;
     else if (!strcmp(name, "batch")) *value = s->d.B;
     else if (!strcmp(name, "max_resident_knots")) *value = s->plan.max_knots_per_wg * (s->num_cus < 256 ? s->num_cus : 256);
@@ -577,6 +585,37 @@ extern "C" int gato_compute_dz(gato_solver *s, const void *d_Ginv_dense, const v
     return s->ops->compute_dz(s->d, d_Ginv_dense, d_C_dense, d_g, d_lambda, d_dz, (hipStream_t)stream);
 }
 
+// A1 + A2 + A3 for the whole-solve entries: ONE fused launch (assemble_kernel) where launch latency is what
+// counts, the stage kernels one by one where throughput does (the fused workgroup recomputes its left neighbour's
+// Schur block; option asm_mode: 0 = auto, 1 = stage kernels, 2 = fused).
+static int assemble(gato_solver *s, int mode, const int *G_row, const int *G_col, const void *G_val, const int *C_row,
+                    const int *C_col, const void *C_val, const void *C_dense, const void *d_g, const void *d_c, double rho,
+                    hipStream_t st)
+{
+    int rc;
+    const bool fused = s->asm_mode == 2 || (s->asm_mode == 0 && (long long)s->d.K * s->d.B <= 2ll * s->num_cus);   // one round of workgroups: measured crossover, DESIGN.md 3.3
+    s->last_asm_fused = fused;
+    if (!fused) {
+        if (mode == 0) rc = gato_convert(s, G_row, G_col, G_val, C_row, C_col, C_val, rho, s->G_dense, s->C_dense, st);
+        else rc = s->ops->add_rho(s->d, G_val, rho, s->G_dense, st);
+        if (rc) return rc;
+        if ((rc = gato_form_schur(s, s->G_dense, C_dense, d_g, d_c, s->Sbd, s->Pbd, s->gamma, s->Ginv, st))) return rc;
+        return gato_form_ss(s, s->Sbd, s->Pbd, st);
+    }
+    if (mode == 0 && s->d.B > 1 && (s->d.nnzG <= 0 || s->d.nnzC <= 0)) {
+        set_error("a batched solver needs the per-system nnz (gato_linsys_device_batched, or options batch_nnz_G / batch_nnz_C)");
+        return GATO_EINVAL;
+    }
+    AsmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = mode;
+    a.G_row = G_row; a.G_col = G_col; a.G_val = G_val; a.C_row = C_row; a.C_col = C_col; a.C_val = C_val;
+    a.rho = rho; a.g = d_g; a.c = d_c;
+    a.Gd = s->G_dense; a.Cd = const_cast<void *>(C_dense); a.Ginv = s->Ginv; a.Sbd = s->Sbd; a.Pbd = s->Pbd; a.gamma = s->gamma;
+    a.stamps = s->stamp_asm ? (unsigned long long *)s->sw.scalars + 8 : nullptr;
+    return s->ops->assemble(s->d, a, st);
+}
+
 extern "C" int gato_linsys_device(gato_solver *s, const int *d_G_row, const int *d_G_col, const void *d_G_val,
                                   const int *d_C_row, const int *d_C_col, const void *d_C_val, const void *d_g,
                                   const void *d_c, double exit_tol, int max_iters, double rho, void *d_lambda,
@@ -585,9 +624,7 @@ extern "C" int gato_linsys_device(gato_solver *s, const int *d_G_row, const int 
     int rc;
     void *lam = d_lambda ? d_lambda : s->lambda;
     void *dz = d_dz ? d_dz : s->dz;
-    if ((rc = gato_convert(s, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, rho, s->G_dense, s->C_dense, stream))) return rc;
-    if ((rc = gato_form_schur(s, s->G_dense, s->C_dense, d_g, d_c, s->Sbd, s->Pbd, s->gamma, s->Ginv, stream))) return rc;
-    if ((rc = gato_form_ss(s, s->Sbd, s->Pbd, stream))) return rc;
+    if ((rc = assemble(s, 0, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, s->C_dense, d_g, d_c, rho, (hipStream_t)stream))) return rc;
     if ((rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream))) return rc;
     if ((rc = gato_compute_dz(s, s->Ginv, s->C_dense, d_g, lam, dz, stream))) return rc;
     return GATO_OK;
@@ -600,9 +637,7 @@ extern "C" int gato_linsys_device_blocks(gato_solver *s, const void *d_G_blocks,
     int rc;
     void *lam = d_lambda ? d_lambda : s->lambda;
     void *dz = d_dz ? d_dz : s->dz;
-    if ((rc = s->ops->add_rho(s->d, d_G_blocks, rho, s->G_dense, (hipStream_t)stream))) return rc;
-    if ((rc = gato_form_schur(s, s->G_dense, d_C_blocks, d_g, d_c, s->Sbd, s->Pbd, s->gamma, s->Ginv, stream))) return rc;
-    if ((rc = gato_form_ss(s, s->Sbd, s->Pbd, stream))) return rc;
+    if ((rc = assemble(s, 2, nullptr, nullptr, d_G_blocks, nullptr, nullptr, nullptr, d_C_blocks, d_g, d_c, rho, (hipStream_t)stream))) return rc;
     if ((rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream))) return rc;
     return gato_compute_dz(s, s->Ginv, d_C_blocks, d_g, lam, dz, stream);
 }

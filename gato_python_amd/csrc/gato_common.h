@@ -161,6 +161,19 @@ int launch_add_rho(const Dims &d, const T *G_in, T rho, T *Gd, hipStream_t st);
 template <typename T, int S, int C>
 int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const T *c, T *Sbd, T *Pbd,
                       T *gamma, T *Ginv, hipStream_t st);
+// Fused assembly (A1 + A2 + A3) in one launch: see assemble_kernel in gato_assembly.hip.
+struct AsmArgs {
+    int mode;                        // 0: CSR in, G_dense/C_dense out; 1: G_dense/C_dense in; 2: G blocks in (+rho) -> G_dense, C_dense in
+    const int *G_row, *G_col, *C_row, *C_col;
+    const void *G_val, *C_val;       // mode 2: G_val = the caller's G blocks
+    double rho;
+    const void *g, *c;
+    void *Gd, *Cd, *Ginv, *Sbd, *Pbd, *gamma;
+    unsigned long long *stamps;      // diagnostic (option stamp_asm): one workgroup's phase boundaries, 100 MHz ticks
+};
+template <typename T, int S, int C>
+int launch_assemble(const Dims &d, const AsmArgs &a, hipStream_t st);
+
 template <typename T, int S, int C>
 int launch_form_ss(const Dims &d, const T *Sbd, T *Pbd, hipStream_t st);
 template <typename T, int S, int C>
@@ -230,6 +243,7 @@ struct Ops {
     int (*form_schur)(const Dims &, const void *, const void *, const void *, const void *, void *, void *,
                       void *, void *, hipStream_t);
     int (*form_ss)(const Dims &, const void *, void *, hipStream_t);
+    int (*assemble)(const Dims &, const AsmArgs &, hipStream_t);
     int (*compute_dz)(const Dims &, const void *, const void *, const void *, const void *, void *,
                       hipStream_t);
     int (*pcg_plan)(PcgPlan *);

@@ -149,6 +149,23 @@ class Solver:
     def buffer_ptr(self, which: int) -> int:
         return int(_lib.lib().gato_solver_buffer(self._h, which))
 
+    _BUFFERS = dict(G_dense=0, C_dense=1, Ginv=2, S=3, Pinv=4, gamma=5, lam=6, dz=7)
+
+    def read_buffer(self, name: str):
+        """Host copy of one of the solver's own work buffers (all systems of a batch), for tests and debugging."""
+        which = self._BUFFERS[name]
+        n = {0: self.sizes["G_dense"], 1: self.sizes["C_dense"], 2: self.sizes["G_dense"], 3: self.sizes["bd"],
+             4: self.sizes["bd"], 5: self.sizes["sk"], 6: self.sizes["sk"], 7: self.N}[which] * self.batch
+        out = np.empty(n, self.np_dtype)
+        if n == 0:
+            return out
+        torch.cuda.synchronize(self.device)
+        rc = ct.CDLL("libamdhip64.so").hipMemcpy(out.ctypes.data_as(ct.c_void_p), ct.c_void_p(self.buffer_ptr(which)),
+                                                 ct.c_size_t(out.nbytes), 2)
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy failed: {rc}")
+        return out
+
     def pcg_last_ms(self) -> float:
         """Device time of the last PCG launch (needs set_option("time_pcg", 1))."""
         ms = ct.c_float()

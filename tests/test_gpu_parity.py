@@ -486,3 +486,70 @@ def test_eta_history(opts):
     tol = 1e-5 if opts.get("pcg_variant") else 1e-8
     assert np.allclose(hist[:m], ref[:m], rtol=tol, atol=1e-12), (hist[:5], ref[:5])
     sol.close()
+
+
+@pytest.mark.parametrize("S,C,K,seed,dq", CASES + [(14, 7, 600, 3, False), (12, 6, 33, 4, True)])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_fused_assembly_is_bit_identical_to_the_stage_kernels(S, C, K, seed, dq, dt):
+    """gato_linsys_device assembles small problems in ONE launch (CSR gather + inversions + Schur + stair); the stage
+    entries (gato_convert / gato_form_schur / gato_form_ss, checked against the oracle above) are separate launches.
+    Same arithmetic per block, so every work buffer must match bit for bit."""
+    s = system(S, C, K, seed, dq) if K > 1 else synth.blocks_to_csr(*synth.make_blocks(S, C, 1, seed, dq))
+    names = ["G_dense", "C_dense", "Ginv", "S", "Pinv", "gamma", "lam", "dz"]
+    ref = None
+    for opts in (dict(asm_mode=1), dict(asm_mode=2)):
+        sol = make_solver(S, C, K, dt)
+        for k, v in opts.items():
+            sol.set_option(k, v)
+        dev = sol.upload_system(s)
+        for _ in range(2):
+            sol.linsys(*dev, 1e-8, 50, s.rho)
+            sol.check_status()
+        got = {n: sol.read_buffer(n) for n in names}
+        assert sol.get_option("last_asm_fused") == (1 if opts["asm_mode"] == 2 else 0)
+        sol.close()
+        if ref is None:
+            ref = got
+            continue
+        for n in names:
+            assert np.array_equal(got[n], ref[n], equal_nan=True), (opts, n)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_fused_assembly_batched_and_blocks(dt):
+    S, C, K, B = 14, 7, 20, 9
+    systems = [synth.make_system(S, C, K, seed=10 + b, dense_q=False) for b in range(B)]
+    names = ["G_dense", "Ginv", "S", "Pinv", "gamma", "lam", "dz"]
+    from gato_python_amd.solver import Solver
+    ref = None
+    for mode in (1, 2):
+        sol = Solver(S, C, K, dt, batch=B)
+        sol.set_option("asm_mode", mode)
+        dev = sol.upload_batch(systems)
+        lam, dz = sol.new(B * S * K), sol.new(B * sol.N)
+        sol.linsys_batched(*dev, 1e-8, 60, systems[0].rho, lam, dz)
+        sol.check_status()
+        got = {n: sol.read_buffer(n) for n in names if n not in ("lam", "dz")}
+        got["lam"], got["dz"] = host(lam), host(dz)
+        sol.close()
+        if ref is None:
+            ref = got
+            continue
+        for n in names:
+            assert np.array_equal(got[n], ref[n]), n
+    # direct block input (mode 2 of the fused launch) against the stage kernels
+    s = systems[0]
+    Gd_o, Cd_o = co.convert(*s.csr_args()[:6], S, C, K, 0.0, dt)
+    ref = None
+    for mode in (1, 2):
+        sol = make_solver(S, C, K, dt)
+        sol.set_option("asm_mode", mode)
+        sol.linsys_blocks(sol.to_device(Gd_o), sol.to_device(Cd_o), sol.to_device(s.g), sol.to_device(s.c), 1e-8, 60, s.rho)
+        sol.check_status()
+        got = {n: sol.read_buffer(n) for n in names}
+        sol.close()
+        if ref is None:
+            ref = got
+            continue
+        for n in names:
+            assert np.array_equal(got[n], ref[n]), n
