@@ -212,7 +212,7 @@ def main():
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or (args.workload or "").startswith(("sharded", "batched")):
+    if args.gpus > 1 or world > 1 or (args.workload or "").startswith(("sharded", "batched", "replicas")):
         from gato_python_amd import dist_bench
         return dist_bench.main(args)
 

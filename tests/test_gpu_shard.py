@@ -63,3 +63,17 @@ def test_bench_batched_leg_world1():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["scaling"] == "weak" and d["value"] > 1e6 and d["config"]["systems_per_gpu"] == 512
+
+
+def test_bench_default_multi_gpu_line_world1():
+    """What `bench.py --gpus N` prints for N > 1 (one system per rank + the sharded solve riding along), with one rank."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29535", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "replicas",
+                        "--steps", "5", "--warmup", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["scaling"] == "weak" and d["n_gpus"] == 1 and d["value"] > 1e5 and d["dtype"] == "f64"
+    assert d["config"]["workload"] == "iiwa_14_7_k50_f64" and 0 < d["roofline"]["frac"] < 1
+    sh = d["sharded"]
+    assert sh["scaling"] == "strong" and sh["config"]["workload"] == "sharded_k4096_f32" and sh["value"] > 0
+    assert sh["parity"]["lam_rel_err_vs_single_gpu"] < 5e-3
