@@ -127,6 +127,9 @@ struct gato_solver {
         const char *S_full, *P_full, *gamma_full;
     } sh;
     char *ghosts;   // [r|p][ping-pong][left|right][S]
+    unsigned pcg_epoch;        // next free hand-off epoch (resident kernels)
+    int pcg_launch_id;
+    size_t slots_bytes;
     int asm_mode;       // option: 0 = auto, 1 = stage kernels one by one (convert / invert / schur / stair), 2 = fused launch
     int last_asm_fused, stamp_asm;
     double *eta_hist;   // eta after init and after every iteration (option record_eta), GATO_ETA_HIST_MAX + 1 entries
@@ -264,6 +267,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     const int slot_g = pcg_slot_granules(S, (int)e) > pcg_slot_granules_cg1(S, (int)e) ? pcg_slot_granules(S, (int)e)
                                                                                         : pcg_slot_granules_cg1(S, (int)e);
     const size_t o_slots = take((size_t)2 * 256 * slot_g * 8);
+    s->slots_bytes = (size_t)2 * 256 * slot_g * 8;
     const size_t nb = (size_t)B;
     const size_t o_G = take(d.g_dense() * e * nb), o_C = take(d.c_dense() * e * nb), o_Gi = take(d.g_dense() * e * nb);
     const size_t o_S = take(d.bd() * e * nb), o_P = take(d.bd() * e * nb), o_gam = take(d.sk() * e * nb);
@@ -329,6 +333,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "pcg_threads")) s->pcg_threads = value;
     else if (!strcmp(name, "pcg_groups")) s->pcg_groups = value;
     else if (!strcmp(name, "asm_mode")) s->asm_mode = value;
+    else if (!strcmp(name, "pcg_epoch")) s->pcg_epoch = (unsigned)value;      // test hook: place the counter near its wrap
     else if (!strcmp(name, "stamp_asm")) s->stamp_asm = value;
     else if (!strcmp(name, "stamp_asm")) s->stamp_asm = value;
     else if (!strcmp(name, "stamp_pcg")) s->stamp_pcg = value;
@@ -527,6 +532,16 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         }
         a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
         a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
+        // hand-off epochs: each launch gets a fresh range (two reductions per iteration plus the initial one)
+        const unsigned need = max_iters > 0x3FFFFFF0 ? 0x80000000u : 2u * (unsigned)max_iters + 8u;
+        if (s->pcg_epoch > 0xFFFFFFFFu - need - 8u) {            // counter about to wrap: start over on zeroed granules
+            GATO_HIP_CHECK(hipMemsetAsync(s->slots, 0, s->slots_bytes, st));
+            s->pcg_epoch = 0;
+        }
+        a.epoch0 = s->pcg_epoch;
+        s->pcg_epoch += need;
+        if (++s->pcg_launch_id <= 0) s->pcg_launch_id = 1;
+        a.launch_id = s->pcg_launch_id;
         a.final_eta = s->final_eta;
         a.eta_hist = (s->record_eta && max_iters <= GATO_ETA_HIST_MAX) ? s->eta_hist : nullptr;
         a.timeout_ticks = 200000000ull;   // 2 s at 100 MHz
@@ -575,7 +590,7 @@ extern "C" int gato_pcg_status(gato_solver *s, int *status)
     int v = 0;
     GATO_HIP_CHECK(hipMemcpy(&v, s->status, sizeof(int), hipMemcpyDeviceToHost));
     if (status) *status = v;
-    if (v != 0) { set_error("pcg: in-kernel hand-off timed out"); return GATO_ETIMEOUT; }
+    if (v != 0 && v == s->pcg_launch_id) { set_error("pcg: in-kernel hand-off timed out"); return GATO_ETIMEOUT; }
     return GATO_OK;
 }
 

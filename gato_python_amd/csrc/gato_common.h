@@ -118,7 +118,9 @@ struct PcgLaunch {
     int knots_per_wg;            // contiguous knots owned by each workgroup (last may own fewer)
     int groups;                  // W = gridDim.x
     int threads;                 // blockDim.x (multiple of 64, >= knots_per_wg * S)
-    unsigned long long *slots;   // hand-off granules, zeroed before every launch
+    unsigned long long *slots;   // hand-off granules: every 8-byte word {epoch, payload}; epochs only grow, so no re-zeroing
+    unsigned epoch0;             // this launch uses epochs epoch0+1 .. (the solver hands out disjoint ranges)
+    int launch_id;               // > 0; a timed-out hand-off stores it into *status (stale ids of earlier launches are ignored)
     int *iters;                  // device
     int *status;                 // device, 0 ok / 1 timeout
     double *final_eta;           // device (optional)

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
 
     T lam = (T)0, r = own ? xr[(jl + 1) * SP + r_] : (T)0;
     T p = (T)0, s = (T)0, u = (T)0, w = (T)0;
-    unsigned epoch = 0;
+    unsigned epoch = a.epoch0;
     bool aborted = false;
     const unsigned long long t_limit = a.timeout_ticks;
 
@@ -171,12 +171,12 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
                 if (__all(ok)) break;
                 if ((spin & 255u) == 255u) {
                     const bool late = __builtin_amdgcn_s_memrealtime() - tstart > t_limit;
-                    const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
                     if (late || other) { fail = true; break; }
                 }
             }
             if (fail && lane == 0) {
-                __hip_atomic_store(g_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_abort = 1;
             }
             T a0 = (T)0, a1 = (T)0;
@@ -276,14 +276,6 @@ int launch_pcg_cg1(const PcgLaunch &a, hipStream_t st)
         return GATO_EINVAL;
     }
     if (a.batch > 1 && a.groups != 1) { set_error("pcg_cg1: a batch needs one workgroup per system"); return GATO_EINVAL; }
-    if (a.groups > 1) {
-        const size_t bytes = (size_t)2 * a.groups * pcg_slot_granules_cg1(S, (int)sizeof(T)) * 8;
-        if ((const char *)a.slots == (const char *)a.status + 256) GATO_HIP_CHECK(hipMemsetAsync(a.status, 0, 256 + bytes, st));
-        else {
-            GATO_HIP_CHECK(hipMemsetAsync(a.slots, 0, bytes, st));
-            GATO_HIP_CHECK(hipMemsetAsync(a.status, 0, sizeof(int), st));
-        }
-    }
     if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
     const int nblocks = a.batch > 1 ? a.batch : (a.xcd_pack > 0 ? 8 * ((a.groups + a.xcd_pack - 1) / a.xcd_pack) : a.groups);
     hipLaunchKernelGGL((pcg_cg1_kernel<T, S, MAXT>), dim3(nblocks), dim3(a.threads), 0, st, a);

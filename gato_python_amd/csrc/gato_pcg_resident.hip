@@ -177,7 +177,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         t_begin = t_prev = __builtin_amdgcn_s_memtime();
         rt_begin = __builtin_amdgcn_s_memrealtime();
     }
-    unsigned epoch = 0;
+    unsigned epoch = a.epoch0;
     T eta = (T)0, eta_new = (T)0;
     int iters = a.max_iters;
     const T tol = (T)a.exit_tol;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                     if (__all(ok)) break;
                     if ((spin & 255u) == 255u) {
                         const bool late = __builtin_amdgcn_s_memrealtime() - t0 > t_limit;
-                        const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                        const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
                         if (late || other) { fail = true; break; }
                     }
                 }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 const T hv = Gr::decode(hraw);
                 if (fail) {
                     if (lane == 0) {
-                        __hip_atomic_store(g_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         s_abort = 1;
                     }
                 }
@@ -567,18 +567,8 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
                   a.groups, a.knots_per_wg, a.threads, MAXT);
         return GATO_EINVAL;
     }
-    const size_t slot_bytes = (size_t)2 * a.groups * pcg_slot_granules(S, (int)sizeof(T)) * 8;
-    // hand-off state is re-initialised before every launch (one memset node: the status word sits right
-    // behind the granules in the solver arena); a single workgroup polls nothing and clears the word itself
-    if (a.groups > 1) {
-        const char *st0 = (const char *)a.status;
-        if ((const char *)a.slots == st0 + 256) {
-            GATO_HIP_CHECK(hipMemsetAsync(a.status, 0, 256 + slot_bytes, st));
-        } else {
-            GATO_HIP_CHECK(hipMemsetAsync(a.slots, 0, slot_bytes, st));
-            GATO_HIP_CHECK(hipMemsetAsync(a.status, 0, sizeof(int), st));
-        }
-    }
+    // no re-initialisation of the hand-off area: granules carry epochs from the solver's ever-growing counter and
+    // the status word is matched against this launch's id
     if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
     const int nblocks = a.batch > 1 ? a.batch
                       : (a.xcd_pack > 0 ? 8 * ((a.groups + a.xcd_pack - 1) / a.xcd_pack) : a.groups);

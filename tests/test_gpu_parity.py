@@ -553,3 +553,35 @@ def test_fused_assembly_batched_and_blocks(dt):
             continue
         for n in names:
             assert np.array_equal(got[n], ref[n]), n
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_handoff_epochs_across_launches_and_counter_wrap(variant):
+    """Multi-workgroup launches never re-zero the hand-off granules: each launch gets a fresh epoch range from the
+    solver's counter.  Repeated solves, a change of launch geometry in between, and the counter's wrap (test hook
+    pcg_epoch) must all give the first launch's result bit for bit."""
+    S, C, K, dt = 14, 7, 600, np.float32
+    s = system(S, C, K, 21)
+    sol = make_solver(S, C, K, dt)
+    sol.set_option("pcg_variant", variant)
+    dev = sol.upload_system(s)
+    lam, dz = sol.new(S * K), sol.new(sol.N)
+
+    def solve():
+        sol.linsys(*dev, 1e-7, 80, s.rho, lam, dz)
+        sol.check_status()
+        return host(lam).copy()
+
+    ref = solve()
+    assert sol.get_option("last_groups") > 1
+    for _ in range(3):
+        assert np.array_equal(solve(), ref)
+    sol.set_option("pcg_threads", 256)                 # other geometry: other slot layout over the same granules
+    other = solve()
+    assert rel(other, ref) < 1e-3
+    sol.set_option("pcg_threads", 0)
+    assert np.array_equal(solve(), ref)
+    sol.set_option("pcg_epoch", -300)                  # 300 epochs before 2^32: the next launch must start over
+    for _ in range(3):
+        assert np.array_equal(solve(), ref)
+    sol.close()

@@ -8,7 +8,7 @@ from gato_python_amd.solver import Solver
 names = ["spmv S.p", "reduce v (+handoff)", "update lam,r + barrier", "spmv Pinv.r", "reduce eta (+handoff)", "update p + barrier"]
 for (S, C, K, dt, thr) in [(14, 7, 50, np.float32, 0), (14, 7, 50, np.float64, 0), (14, 7, 512, np.float32, 512), (14, 7, 4096, np.float32, 512)]:
     s = synth.make_system(S, C, K, seed=0)
-    sol = Solver(S, C, K, dt); sol.set_option("pcg_threads", thr); sol.set_option("stamp_pcg", 1)
+    sol = Solver(S, C, K, dt); sol.set_option("pcg_threads", thr); sol.set_option("stamp_pcg", 1); sol.set_option("no_pair", 1)
     dev = sol.upload_system(s); lam, dz = sol.new(S * K), sol.new(sol.N)
     iters = 100
     for _ in range(2): sol.linsys(*dev, 0.0, iters, s.rho, lam, dz)
