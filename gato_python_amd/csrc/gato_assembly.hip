@@ -25,52 +25,6 @@ namespace {
 
 constexpr int WAVE = 64;
 
-// ---- A1 ------------------------------------------------------------------------------------
-// The reference walks each CSR row with one thread (gato_schur.cuh:674-743): a chain of dependent loads per
-// entry.  Here a thread owns ONE (row, slot) pair - slot = position inside the row, rows longer than SLOTS are
-// walked with stride SLOTS - so a solve's scatter is two dependent loads deep (indptr -> col/val -> store).
-// Same arithmetic and same destination per entry as the reference; outputs pre-zeroed.
-template <typename T, int S, int C>
-__global__ void convert_kernel(const int *__restrict__ G_row, const int *__restrict__ G_col,
-                               const T *__restrict__ G_val, const int *__restrict__ C_row,
-                               const int *__restrict__ C_col, const T *__restrict__ C_val, int K, T rho,
-                               T *__restrict__ Gd, T *__restrict__ Cd, BatchStride bs)
-{
-    constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C;
-    constexpr int SLOTS = 32;
-    G_val += blockIdx.y * bs.nnzG; C_val += blockIdx.y * bs.nnzC;      // batch: shared structure, own values
-    Gd += blockIdx.y * bs.g; Cd += blockIdx.y * bs.c;                                   // >= S + C + 1 for the compiled shapes' C rows
-    const int N = n * K - C;
-    const int SK = S * K;
-    const long long total = (long long)(N + SK) * SLOTS;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const int rr = (int)(t / SLOTS), slot = (int)(t % SLOTS);
-        if (rr < N) {                                           // csr_to_custom_G, gato_schur.cuh:674-704
-            const int row = rr;
-            const int in_set_row = row % n;
-            const size_t set_offset = (size_t)(row / n) * (SS + CC);
-            const int end = G_row[row + 1];
-            for (int it = G_row[row] + slot; it < end; it += SLOTS) {
-                const int col = G_col[it];
-                const int in_set_col = col % n;
-                const T v = G_val[it] + (col == row ? rho : (T)0);
-                if (in_set_col < S) Gd[set_offset + in_set_col * S + in_set_row] = v;
-                else Gd[set_offset + SS + (in_set_col - S) * C + (in_set_row - S)] = v;
-            }
-        } else {                                                // csr_to_custom_C, :707-743
-            const int row = rr - N;
-            if (row < S) continue;
-            const int block_row = row / S - 1;
-            const int end = C_row[row + 1];
-            for (int it = C_row[row] + slot; it < end; it += SLOTS) {
-                const int col = C_col[it];
-                if (col / n > block_row) continue;
-                Cd[(size_t)block_row * (SS + SC) + (col % n) * S + row % S] = C_val[it];
-            }
-        }
-    }
-}
-
 // ---- N4: blocks handed over directly: copy G_dense adding rho on the diagonals of Q_k and R_k (what
 // csr_to_custom_G does to structurally present diagonal entries, gato_schur.cuh:697,:700)
 template <typename T, int S, int C>
@@ -471,6 +425,75 @@ __device__ __forceinline__ int row_of_entry(const int *ptr, int nrows, int e)
     return lo;
 }
 
+// ---- A1 (+ the inversions of A2): one workgroup per knot ----------------------------------------------------------
+// The reference walks each CSR row with one thread (gato_schur.cuh:674-743): a chain of dependent loads per entry and
+// scattered 4-byte stores into pre-zeroed outputs.  Here the workgroup of knot k gathers the knot's entries - G rows
+// of knot k and C row-block k+1 are contiguous index ranges - a thread per ENTRY, into dense LDS blocks and writes
+// Q_k, R_k, [A_k | B_k] out whole: no memset, coalesced stores, the batch shares the index arrays.  With Ginv given,
+// two wavefronts then invert Q_k and R_k from LDS (what invert_G_kernel does after a round trip through HBM).
+// Same arithmetic and same destination per entry as the reference.
+template <typename T, int S, int C, int NT>
+__global__ __launch_bounds__(NT) void gather_kernel(const int *__restrict__ G_row, const int *__restrict__ G_col,
+                                                    const T *__restrict__ G_val, const int *__restrict__ C_row,
+                                                    const int *__restrict__ C_col, const T *__restrict__ C_val, int K, T rho,
+                                                    T *__restrict__ Gd, T *__restrict__ Cd, T *__restrict__ Ginv, BatchStride bs)
+{
+    constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C, ABS = SS + SC;
+    static_assert(NT >= 2 * WAVE, "two inversions side by side");
+    __shared__ T blk[SS + CC + ABS];                                          // Q_k | R_k | A_k | B_k
+    __shared__ int sPtrG[n + 1], sPtrC[S + 1];
+    T *sQ = blk, *sR = blk + SS, *sAB = blk + SS + CC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    G_val += blockIdx.y * bs.nnzG; C_val += blockIdx.y * bs.nnzC;            // batch: shared structure, own values
+    Gd += blockIdx.y * bs.g; Cd += blockIdx.y * bs.c;
+    if (Ginv) Ginv += blockIdx.y * bs.g;
+    for (int k = blockIdx.x; k < K; k += gridDim.x) {
+        const bool last = k == K - 1;
+        const int r0 = k * n, nrG = last ? S : n;
+        const int c0 = (k + 1) * S, nrC = last ? 0 : S;
+        __syncthreads();
+        for (int i = tid; i <= nrG; i += NT) sPtrG[i] = G_row[r0 + i];
+        if (nrC) for (int i = tid; i <= nrC; i += NT) sPtrC[i] = C_row[c0 + i];
+        for (int i = tid; i < SS + CC + ABS; i += NT) blk[i] = (T)0;
+        __syncthreads();
+        const int eG0 = sPtrG[0], nG = sPtrG[nrG] - eG0;
+        const int eC0 = nrC ? sPtrC[0] : 0, nC = nrC ? sPtrC[nrC] - eC0 : 0;
+        constexpr int U = 4;
+        for (int t0 = tid; t0 < nG + nC; t0 += NT * U) {
+            int col[U];
+            T val[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * NT;
+                if (t < nG) { col[u] = G_col[eG0 + t]; val[u] = G_val[eG0 + t]; }
+                else if (t < nG + nC) { col[u] = C_col[eC0 + (t - nG)]; val[u] = C_val[eC0 + (t - nG)]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * NT;
+                if (t < nG) {                                              // csr_to_custom_G, gato_schur.cuh:674-704
+                    const int isr = row_of_entry(sPtrG, nrG, eG0 + t);
+                    const int isc = col[u] % n;
+                    const T v = val[u] + (col[u] == r0 + isr ? rho : (T)0);
+                    if (isc < S) { if (isr < S) sQ[isc * S + isr] = v; }
+                    else if (isr >= S) sR[(isc - S) * C + (isr - S)] = v;
+                } else if (t < nG + nC) {                                  // csr_to_custom_C, :707-743
+                    const int i = row_of_entry(sPtrC, nrC, eC0 + (t - nG));
+                    if (col[u] / n <= k) sAB[(col[u] % n) * S + i] = val[u];
+                }
+            }
+        }
+        __syncthreads();
+        const size_t gk = (size_t)k * (SS + CC);
+        for (int i = tid; i < SS + (last ? 0 : CC); i += NT) Gd[gk + i] = blk[i];
+        if (!last) for (int i = tid; i < ABS; i += NT) Cd[(size_t)k * ABS + i] = sAB[i];
+        if (Ginv) {
+            if (wave == 0) invert_to<T, S>(sQ, Ginv + gk, lane, (T)1);
+            else if (wave == 1 && !last) invert_to<T, C>(sR, Ginv + gk + SS, lane, (T)1);
+        }
+    }
+}
+
 template <typename T, int S, int C, int NT>
 __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStride bs)
 {
@@ -729,23 +752,11 @@ __global__ __launch_bounds__(WAVE) void dz_kernel(const T *__restrict__ Ginv, co
 
 template <typename T, int S, int C>
 int launch_convert(const Dims &d, const int *G_row, const int *G_col, const T *G_val, const int *C_row,
-                   const int *C_col, const T *C_val, T rho, T *Gd, T *Cd, hipStream_t st)
+                   const int *C_col, const T *C_val, T rho, T *Gd, T *Cd, T *Ginv, hipStream_t st)
 {
-    // one memset when the two outputs sit back to back in the solver's arena (they do in gato_linsys_device)
-    const char *g_end = (const char *)(Gd + d.g_dense() * d.B);
-    const char *c_end = (const char *)(Cd + d.c_dense() * d.B);
-    if ((const char *)Cd >= g_end && (const char *)Cd - g_end <= 4096 && d.c_dense()) {
-        GATO_HIP_CHECK(hipMemsetAsync(Gd, 0, (size_t)(c_end - (const char *)Gd), st));
-    } else {
-        GATO_HIP_CHECK(hipMemsetAsync(Gd, 0, d.g_dense() * d.B * sizeof(T), st));
-        if (d.c_dense()) GATO_HIP_CHECK(hipMemsetAsync(Cd, 0, d.c_dense() * d.B * sizeof(T), st));
-    }
-    const long long work = ((long long)d.N() + (long long)d.sk()) * 32;
-    const int threads = 256;
-    const long long want = (work + threads - 1) / threads;
-    const int blocks = (int)(want < 4096 ? want : 4096);
-    hipLaunchKernelGGL((convert_kernel<T, S, C>), dim3(blocks, d.B), dim3(threads), 0, st, G_row, G_col, G_val, C_row,
-                       C_col, C_val, d.K, rho, Gd, Cd, batch_stride(d));
+    constexpr int NT = 128;
+    hipLaunchKernelGGL((gather_kernel<T, S, C, NT>), dim3(d.K < (1 << 20) ? d.K : (1 << 20), d.B), dim3(NT), 0, st, G_row, G_col,
+                       G_val, C_row, C_col, C_val, d.K, rho, Gd, Cd, Ginv, batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
     return GATO_OK;
 }
@@ -764,12 +775,14 @@ static inline int knot_grid(int K) { return K < 8192 ? K : 8192; }
 
 template <typename T, int S, int C>
 int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const T *c, T *Sbd, T *Pbd,
-                      T *gamma, T *Ginv, hipStream_t st)
+                      T *gamma, T *Ginv, bool have_inverses, hipStream_t st)
 {
-    const int nblk = (2 * d.K - 1 + 3) / 4;
-    hipLaunchKernelGGL((invert_G_kernel<T, S, C>), dim3(nblk < 8192 ? nblk : 8192, d.B), dim3(256), 0, st, Gd, Ginv, d.K,
-                       batch_stride(d));
-    GATO_HIP_CHECK(hipGetLastError());
+    if (!have_inverses) {
+        const int nblk = (2 * d.K - 1 + 3) / 4;
+        hipLaunchKernelGGL((invert_G_kernel<T, S, C>), dim3(nblk < 8192 ? nblk : 8192, d.B), dim3(256), 0, st, Gd, Ginv, d.K,
+                           batch_stride(d));
+        GATO_HIP_CHECK(hipGetLastError());
+    }
     hipLaunchKernelGGL((schur_kernel<T, S, C>), dim3(knot_grid(d.K), d.B), dim3(WAVE), 0, st, Gd, Ginv, Cd, g, c, d.K,
                        Sbd, Pbd, gamma, batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
@@ -813,16 +826,16 @@ int launch_compute_dz(const Dims &d, const T *Ginv, const T *Cd, const T *g, con
 
 #define X(S_, C_)                                                                                              \
     template int launch_convert<float, S_, C_>(const Dims &, const int *, const int *, const float *, const int *, \
-                                               const int *, const float *, float, float *, float *, hipStream_t); \
+                                               const int *, const float *, float, float *, float *, float *, hipStream_t); \
     template int launch_convert<double, S_, C_>(const Dims &, const int *, const int *, const double *,           \
                                                 const int *, const int *, const double *, double, double *,      \
-                                                double *, hipStream_t);                                          \
+                                                double *, double *, hipStream_t);                                \
     template int launch_add_rho<float, S_, C_>(const Dims &, const float *, float, float *, hipStream_t);             \
     template int launch_add_rho<double, S_, C_>(const Dims &, const double *, double, double *, hipStream_t);          \
     template int launch_form_schur<float, S_, C_>(const Dims &, const float *, const float *, const float *,     \
-                                                  const float *, float *, float *, float *, float *, hipStream_t); \
+                                                  const float *, float *, float *, float *, float *, bool, hipStream_t); \
     template int launch_form_schur<double, S_, C_>(const Dims &, const double *, const double *, const double *, \
-                                                   const double *, double *, double *, double *, double *,       \
+                                                   const double *, double *, double *, double *, double *, bool, \
                                                    hipStream_t);                                                 \
     template int launch_assemble<float, S_, C_>(const Dims &, const AsmArgs &, hipStream_t);                      \
     template int launch_assemble<double, S_, C_>(const Dims &, const AsmArgs &, hipStream_t);                     \

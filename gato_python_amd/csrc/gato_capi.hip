@@ -27,16 +27,16 @@ static Ops make_ops(int dtype)
     Ops o;
     o.S = S; o.C = C; o.dtype = dtype;
     o.convert = [](const Dims &d, const int *gr, const int *gc, const void *gv, const int *cr, const int *cc,
-                   const void *cv, double rho, void *Gd, void *Cd, hipStream_t st) {
-        return launch_convert<T, S, C>(d, gr, gc, (const T *)gv, cr, cc, (const T *)cv, (T)rho, (T *)Gd, (T *)Cd, st);
+                   const void *cv, double rho, void *Gd, void *Cd, void *Gi, hipStream_t st) {
+        return launch_convert<T, S, C>(d, gr, gc, (const T *)gv, cr, cc, (const T *)cv, (T)rho, (T *)Gd, (T *)Cd, (T *)Gi, st);
     };
     o.add_rho = [](const Dims &d, const void *Gin, double rho, void *Gd, hipStream_t st) {
         return launch_add_rho<T, S, C>(d, (const T *)Gin, (T)rho, (T *)Gd, st);
     };
     o.form_schur = [](const Dims &d, const void *Gd, const void *Cd, const void *g, const void *c, void *Sb,
-                      void *Pb, void *gam, void *Gi, hipStream_t st) {
+                      void *Pb, void *gam, void *Gi, bool have_inv, hipStream_t st) {
         return launch_form_schur<T, S, C>(d, (const T *)Gd, (const T *)Cd, (const T *)g, (const T *)c, (T *)Sb,
-                                          (T *)Pb, (T *)gam, (T *)Gi, st);
+                                          (T *)Pb, (T *)gam, (T *)Gi, have_inv, st);
     };
     o.assemble = [](const Dims &d, const AsmArgs &a, hipStream_t st) { return launch_assemble<T, S, C>(d, a, st); };
     o.form_ss = [](const Dims &d, const void *Sb, void *Pb, hipStream_t st) {
@@ -395,14 +395,14 @@ extern "C" int gato_convert(gato_solver *s, const int *d_G_row, const int *d_G_c
         return GATO_EINVAL;
     }
     return s->ops->convert(s->d, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, rho, d_G_dense, d_C_dense,
-                           (hipStream_t)stream);
+                           nullptr, (hipStream_t)stream);
 }
 
 extern "C" int gato_form_schur(gato_solver *s, const void *d_G_dense, const void *d_C_dense, const void *d_g,
                                const void *d_c, void *d_S, void *d_Pinv, void *d_gamma, void *d_Ginv_dense,
                                void *stream)
 {
-    return s->ops->form_schur(s->d, d_G_dense, d_C_dense, d_g, d_c, d_S, d_Pinv, d_gamma, d_Ginv_dense,
+    return s->ops->form_schur(s->d, d_G_dense, d_C_dense, d_g, d_c, d_S, d_Pinv, d_gamma, d_Ginv_dense, false,
                               (hipStream_t)stream);
 }
 
@@ -611,10 +611,12 @@ static int assemble(gato_solver *s, int mode, const int *G_row, const int *G_col
     const bool fused = s->asm_mode == 2 || (s->asm_mode == 0 && (long long)s->d.K * s->d.B <= 2ll * s->num_cus);   // one round of workgroups: measured crossover, DESIGN.md 3.3
     s->last_asm_fused = fused;
     if (!fused) {
-        if (mode == 0) rc = gato_convert(s, G_row, G_col, G_val, C_row, C_col, C_val, rho, s->G_dense, s->C_dense, st);
-        else rc = s->ops->add_rho(s->d, G_val, rho, s->G_dense, st);
+        if (mode == 0) {                 // CSR: the gather launch also inverts Q_k, R_k while they sit in LDS
+            if (s->d.B > 1 && (s->d.nnzG <= 0 || s->d.nnzC <= 0)) return gato_convert(s, G_row, G_col, G_val, C_row, C_col, C_val, rho, s->G_dense, s->C_dense, st);
+            rc = s->ops->convert(s->d, G_row, G_col, G_val, C_row, C_col, C_val, rho, s->G_dense, s->C_dense, s->Ginv, st);
+        } else rc = s->ops->add_rho(s->d, G_val, rho, s->G_dense, st);
         if (rc) return rc;
-        if ((rc = gato_form_schur(s, s->G_dense, C_dense, d_g, d_c, s->Sbd, s->Pbd, s->gamma, s->Ginv, st))) return rc;
+        if ((rc = s->ops->form_schur(s->d, s->G_dense, C_dense, d_g, d_c, s->Sbd, s->Pbd, s->gamma, s->Ginv, mode == 0, st))) return rc;
         return gato_form_ss(s, s->Sbd, s->Pbd, st);
     }
     if (mode == 0 && s->d.B > 1 && (s->d.nnzG <= 0 || s->d.nnzC <= 0)) {

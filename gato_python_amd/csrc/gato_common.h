@@ -157,12 +157,13 @@ struct PcgPlan {
 // Per-(dtype, S, C) kernel launchers, defined in the .hip files and instantiated for GATO_SHAPES.
 template <typename T, int S, int C>
 int launch_convert(const Dims &d, const int *G_row, const int *G_col, const T *G_val, const int *C_row,
-                   const int *C_col, const T *C_val, T rho, T *Gd, T *Cd, hipStream_t st);
+                   const int *C_col, const T *C_val, T rho, T *Gd, T *Cd, T *Ginv /* optional: also invert Q_k, R_k */,
+                   hipStream_t st);
 template <typename T, int S, int C>
 int launch_add_rho(const Dims &d, const T *G_in, T rho, T *Gd, hipStream_t st);
 template <typename T, int S, int C>
 int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const T *c, T *Sbd, T *Pbd,
-                      T *gamma, T *Ginv, hipStream_t st);
+                      T *gamma, T *Ginv, bool have_inverses, hipStream_t st);
 // Fused assembly (A1 + A2 + A3) in one launch: see assemble_kernel in gato_assembly.hip.
 struct AsmArgs {
     int mode;                        // 0: CSR in, G_dense/C_dense out; 1: G_dense/C_dense in; 2: G blocks in (+rho) -> G_dense, C_dense in
@@ -240,10 +241,10 @@ int launch_pcg_streaming(const Dims &d, const T *Sbd, const T *Pbd, const T *gam
 struct Ops {
     int S, C, dtype;
     int (*convert)(const Dims &, const int *, const int *, const void *, const int *, const int *,
-                   const void *, double, void *, void *, hipStream_t);
+                   const void *, double, void *, void *, void *, hipStream_t);
     int (*add_rho)(const Dims &, const void *, double, void *, hipStream_t);
     int (*form_schur)(const Dims &, const void *, const void *, const void *, const void *, void *, void *,
-                      void *, void *, hipStream_t);
+                      void *, void *, bool, hipStream_t);
     int (*form_ss)(const Dims &, const void *, void *, hipStream_t);
     int (*assemble)(const Dims &, const AsmArgs &, hipStream_t);
     int (*compute_dz)(const Dims &, const void *, const void *, const void *, const void *, void *,
