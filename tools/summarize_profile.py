@@ -19,7 +19,7 @@ def short(name):
 
 def one(pattern):
     g = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None          # several runs may have been merged: newest wins
 
 
 stats = one(f"prof_{tag}_stats/*/*_kernel_stats.csv")
