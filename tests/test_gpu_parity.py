@@ -585,3 +585,26 @@ def test_handoff_epochs_across_launches_and_counter_wrap(variant):
     for _ in range(3):
         assert np.array_equal(solve(), ref)
     sol.close()
+
+
+@pytest.mark.parametrize("K", [5, 64, 700])
+def test_kkt_producer_through_the_hip_path(K):
+    """the upstream producer (gato_python_amd/kkt.py: one linearisation of a pendulum OCP around a rolled-out
+    trajectory, the problem family of the reference's own fixture) solved by the HIP path in f64 against the dense solve."""
+    from gato_python_amd import kkt
+    rng = np.random.default_rng(K)
+    plant, dt = kkt.PendulumPlant(), 0.02
+    u = 0.8 * rng.standard_normal((K - 1, 1))
+    x = kkt.rollout(plant, (0.2, 0.0), u, dt)
+    p = kkt.get_kkt(plant, x, u, (0.25, 0.05), (np.pi, 0.0), dt, np.diag([1.0, 0.3]), np.array([[0.1]]), np.diag([100.0, 30.0]))
+    sol = make_solver(2, 1, K, np.float64)
+    dev = sol.upload_system(p)
+    lam, dz = sol.new(2 * K), sol.new(sol.N)
+    sol.linsys(*dev, 1e-18, 2000, p.rho, lam, dz)
+    sol.check_status()
+    dz_d, lam_d = synth.dense_kkt_solve(p)
+    assert np.abs(host(dz) - dz_d).max() < 1e-6 * max(1.0, np.abs(dz_d).max())
+    assert rel(host(lam), lam_d) < 1e-6
+    lam_o, dz_o, it_o = o.linsys_solve(*p.csr_args(), 2, 1, K, 1e-18, 2000, p.rho, np.float64)[:3]
+    assert rel(host(lam), lam_o) < 1e-8
+    sol.close()
