@@ -236,7 +236,10 @@ def main():
                      "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": committed_traffic(name),
                      "kernel": "pcg_" + str(res["pcg_mode"]), "launch_ms": res["pcg_launch_ms"],
                      "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_launch"],
-                     "pcg_only_iterations_per_s": res["pcg_iters_per_s"]},
+                     "pcg_only_iterations_per_s": res["pcg_iters_per_s"],
+                     "regime": "matrices register/LDS-resident on one CU: the launch reads them from HBM once (traffic), "
+                               "an iteration is bound by its two dependent block reductions and LDS operand reads, not by "
+                               "HBM (DESIGN.md 3.1); the HBM-bound run of this path is sweep entry iiwa_14_7_k131072_f32"},
     }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(sysm, dt)

@@ -48,51 +48,6 @@ __device__ __forceinline__ void copy_in(T *dst, const T *__restrict__ src, int n
     for (int i = lane; i < n; i += WAVE) dst[i] = src[i];
 }
 
-// Gauss-Jordan inverse, no pivoting (invertMatrix, gato_utils.cuh:468-586): A (n x n col-major in
-// LDS) is destroyed, Ainv receives A^-1.  tmp: 3n elements.
-template <typename T, int n>
-__device__ void gj_inverse(T *A, T *Ainv, T *tmp, int lane)
-{
-    for (int i = lane; i < n * n; i += WAVE) Ainv[i] = (T)((i % n) == (i / n));
-    wave_sync();
-    T *colv = tmp, *rowA = tmp + n, *rowI = tmp + 2 * n;
-    for (int p = 0; p < n; ++p) {
-        // one reciprocal per pivot (the single-matrix overload's pvInv, gato_utils.cuh:476); the pivot row is
-        // saved already scaled, the pivot column already multiplied by 1/pv
-        const T pvinv = (T)1 / A[p + p * n];
-        for (int i = lane; i < n; i += WAVE) {
-            colv[i] = A[i + p * n] * pvinv;
-            rowA[i] = A[p + i * n];
-            rowI[i] = Ainv[p + i * n];
-        }
-        wave_sync();
-        for (int e = lane; e < n * n; e += WAVE) {
-            const int r = e % n, c = e / n;
-            if (r == p) {
-                A[e] = rowA[c] * pvinv;
-                Ainv[e] = rowI[c] * pvinv;
-            } else {
-                const T f = colv[r];
-                A[e] -= f * rowA[c];
-                Ainv[e] -= f * rowI[c];
-            }
-        }
-        wave_sync();
-    }
-}
-
-// out(m x n) = A(m x k) B(k x n) (mat_mat_prod, gato_utils.cuh:609-633); TB: B given as (n x k), use B^T.
-template <typename T, int m, int k, int n, bool TB>
-__device__ __forceinline__ void mm(T *out, const T *A, const T *B, int lane)
-{
-    for (int e = lane; e < m * n; e += WAVE) {
-        const int r = e % m, c = e / m;
-        T res = (T)0;
-#pragma unroll
-        for (int t = 0; t < k; ++t) res = gato::fmaT(A[t * m + r], TB ? B[t * n + c] : B[c * k + t], res);
-        out[e] = res;
-    }
-}
 // out(m) = A(m x n) x (mat_vec_prod, :595-606)
 template <typename T, int m, int n>
 __device__ __forceinline__ void mv(T *out, const T *A, const T *x, int lane)
@@ -794,11 +749,15 @@ int launch_assemble(const Dims &d, const AsmArgs &a, hipStream_t st)
 {
     constexpr int NT = 512;
     typedef AsmLds<T, S, C> L;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GATO_HIP_CHECK(hipFuncSetAttribute((const void *)assemble_kernel<T, S, C, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)L::BYTES));
-        attr_set = true;
+    if (L::BYTES > 48 * 1024) {                      // beyond the default dynamic-LDS limit: opt in once per device
+        static bool attr_set[64] = {};
+        int dev = 0;
+        GATO_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            GATO_HIP_CHECK(hipFuncSetAttribute((const void *)assemble_kernel<T, S, C, NT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
     }
     const int gx = d.K < (1 << 20) ? d.K : (1 << 20);
     hipLaunchKernelGGL((assemble_kernel<T, S, C, NT>), dim3(gx, d.B), dim3(NT), L::BYTES, st, a, d.K, batch_stride(d));
