@@ -264,6 +264,13 @@ def main():
             r["workload"] += "_single_reduction_variant"
             r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
             sweep.append(r)
+        # SURVEY.md 8d run 3: the K=512 system through the STREAMING kernels (matrices re-read every iteration; they fit L2,
+        # so the PMC passes show how little of that reaches HBM) beside the register-resident entry above
+        r, _ = run_single("iiwa_14_7_k512_f32", max(10, args.steps // 10), 3, torch, pcg_mode=2)
+        r["workload"] += "_streaming"
+        r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
+        r["hbm_bytes_per_launch_pmc"] = committed_traffic("iiwa_14_7_k512_f32_streaming")
+        sweep.append(r)
         # batches of independent systems: throughput mode of the K=50 shape
         sweep.append(run_batched(14, 7, 50, np.float64, 512, 10, 2, torch))
         sweep.append(run_batched(14, 7, 50, np.float32, 512, 10, 2, torch))

@@ -79,24 +79,29 @@ for name, (prefix, K) in WL.items():
                                       "fetched bytes (MI355X_MICROARCH.md, HBM section); calibrated here on the K=50 "
                                       "launches, where 2 x FETCH_SIZE equals the S + Pinv bytes read once. launches=%d"
                                       % len(fetch[key]))
-# streaming PCG (K = 131072): traffic of one whole gato_pcg call = sum over its launches (init + 2 per iteration)
-def total(acc, prefix):
-    return sum(sum(v) for k, v in acc.items() if k[0].startswith(prefix))
+# streaming PCG: traffic of one whole gato_pcg call = sum over its launches (init + 2 per iteration).  Two bench
+# entries stream: K = 131072 (20 iterations, 41 launches, the largest grid) and K = 512 (100 iterations, 201 launches)
+def stream_entry(name, pick, launches_per_call, what):
+    keys = [k for k in fetch if k[0].startswith("stream_step_kernel<float, 14") and pick(k[1])]
+    n = sum(len(fetch[k]) for k in keys)
+    if not n:
+        return
+    f_kb = sum(sum(fetch[k]) for k in keys)
+    nw = sum(len(write[k]) for k in keys if k in write)
+    w_kb = sum(sum(write[k]) for k in keys if k in write)
+    traffic[name] = dict(
+        kernel="stream_step_kernel<float, 14, *> (all phases)", launches=n,
+        fetch_size_kb_per_step_launch=f_kb / n, write_size_kb_per_step_launch=w_kb / max(nw, 1),
+        hbm_bytes_per_launch=(2 * f_kb / n + w_kb / max(nw, 1)) * 1024 * launches_per_call,
+        note="per gato_pcg call of %s = %d stream_step launches; (2 x FETCH_SIZE + WRITE_SIZE) averaged per launch x %d; "
+             "16-B-per-lane LDS-DMA stream: the x2 FETCH_SIZE correction applies" % (what, launches_per_call, launches_per_call))
 
 
-def count(acc, prefix):
-    return sum(len(v) for k, v in acc.items() if k[0].startswith(prefix))
-
-
-n_step = count(fetch, "stream_step_kernel<float, 14")
-if n_step:
-    f_kb, w_kb = total(fetch, "stream_step_kernel<float, 14"), total(write, "stream_step_kernel<float, 14")
-    traffic["iiwa_14_7_k131072_f32"] = dict(
-        kernel="stream_step_kernel<float, 14, *> (all phases)", launches=n_step,
-        fetch_size_kb_per_step_launch=f_kb / n_step, write_size_kb_per_step_launch=w_kb / max(count(write, "stream_step_kernel<float, 14"), 1),
-        hbm_bytes_per_launch=(2 * f_kb / n_step + w_kb / max(count(write, "stream_step_kernel<float, 14"), 1)) * 1024 * 41,
-        note="per gato_pcg call of 20 iterations = 41 stream_step launches; (2 x FETCH_SIZE + WRITE_SIZE) averaged per "
-             "launch x 41; 16-B-per-lane LDS-DMA stream: the x2 FETCH_SIZE correction applies")
+grids = sorted({k[1] for k in fetch if k[0].startswith("stream_step_kernel<float, 14")})
+if grids:
+    stream_entry("iiwa_14_7_k131072_f32", lambda g: g == grids[-1], 41, "20 iterations")
+    if len(grids) > 1:
+        stream_entry("iiwa_14_7_k512_f32_streaming", lambda g: g == grids[0], 201, "100 iterations")
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 
 # matrix-core counters of the assembly kernels
@@ -105,7 +110,7 @@ if mf:
     acc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(mf)):
         n = short(r["Kernel_Name"])
-        if any(x in n for x in ("schur_kernel", "ss_kernel", "invert_G_kernel", "pcg_resident", "pcg_single", "stream_step")):
+        if any(x in n for x in ("assemble_kernel", "gather_kernel", "schur_kernel", "ss_kernel", "invert_G_kernel", "pcg_resident", "pcg_single", "stream_step")):
             acc[(n, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     names = ["SQ_INSTS_VALU_MFMA_F32", "SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"]
     with open(os.path.join(out, f"{tag}_mfma_counters.csv"), "w") as f:
