@@ -120,3 +120,16 @@ def test_malformed_csr_is_rejected_on_the_host():
     with pytest.raises(ValueError, match="monotone|indptr"):
         gpu_library.linsys_solve(bad_row, P["G_col"], P["G_val"], P["C_row"], P["C_col"], P["C_val"], P["g_val"],
                                  P["c_val"], P["input_lambda"], 1, 1e-6, 10, False, 1e-3)
+
+
+def test_built_library_is_not_older_than_its_sources():
+    """The in-tree libgato_hip.so travels to the GPU box as built: a stale one would run old kernels there."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "gato_python_amd", "libgato_hip.so")
+    if not os.path.exists(so):
+        pytest.skip("library not built yet (the loader builds it on first use)")
+    srcs = glob.glob(os.path.join(root, "gato_python_amd", "csrc", "*.hip")) + \
+        glob.glob(os.path.join(root, "gato_python_amd", "csrc", "*.h")) + [os.path.join(root, "include", "gato_hip.h")]
+    newest = max(srcs, key=os.path.getmtime)
+    assert os.path.getmtime(so) >= os.path.getmtime(newest), f"{newest} is newer than libgato_hip.so: run make -C gato_python_amd/csrc"
