@@ -117,7 +117,7 @@ struct gato_solver {
     size_t in_bytes;
     char *pin;            // pinned host staging (inputs, then iters | lambda | dz)
     size_t pin_bytes;
-    int last_groups, last_threads, last_mode, last_variant;
+    int last_groups, last_threads, last_mode, last_variant, last_semi;
     int time_pcg, stamp_pcg, ablate, no_single_lds, true_warm_start, no_pair, plan_pair, pcg_variant, xcd_pack;
     hipEvent_t ev_pcg0, ev_pcg1;
     // knot-sharded PCG state (gato_shard_pcg_*)
@@ -127,6 +127,7 @@ struct gato_solver {
         const char *S_full, *P_full, *gamma_full;
     } sh;
     char *ghosts;   // [r|p][ping-pong][left|right][S]
+    int plan_semi, pcg_semi;   // semi-resident launch planned / option (-1 auto, 0 off)
     unsigned pcg_epoch;        // next free hand-off epoch (resident kernels)
     int pcg_launch_id;
     size_t slots_bytes;
@@ -256,6 +257,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     ops->pcg_plan(&s->plan);
     s->pcg_mode = GATO_PCG_AUTO;
     s->xcd_pack = -1;
+    s->pcg_semi = -1;
 
     const Dims &d = s->d;
     const size_t e = s->esz;
@@ -333,6 +335,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "pcg_threads")) s->pcg_threads = value;
     else if (!strcmp(name, "pcg_groups")) s->pcg_groups = value;
     else if (!strcmp(name, "asm_mode")) s->asm_mode = value;
+    else if (!strcmp(name, "pcg_semi")) s->pcg_semi = value;
     else if (!strcmp(name, "pcg_epoch")) s->pcg_epoch = (unsigned)value;      // test hook: place the counter near its wrap
     else if (!strcmp(name, "stamp_asm")) s->stamp_asm = value;
     else if (!strcmp(name, "stamp_asm")) s->stamp_asm = value;
@@ -377,6 +380,7 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "last_variant")) *value = s->last_variant;
     else if (!strcmp(name, "asm_mode")) *value = s->asm_mode;
     else if (!strcmp(name, "last_asm_fused")) *value = s->last_asm_fused;
+    else if (!strcmp(name, "last_semi")) *value = s->last_semi;
     else if (!strcmp(name, "num_cus")) *value = s->num_cus;
     else if (!strcmp(name, "batch")) *value = s->d.B;
     else if (!strcmp(name, "max_resident_knots")) *value = s->plan.max_knots_per_wg * (s->num_cus < 256 ? s->num_cus : 256);
@@ -420,6 +424,7 @@ static int plan_resident(gato_solver *s, int *groups, int *threads, int *kpw)
     int t = s->pcg_threads;
     int g = s->pcg_groups;
     const int maxT = s->plan.max_threads;
+    s->plan_semi = 0;
     if (t > 0) {
         t = (t + 63) / 64 * 64;
         if (t > maxT) t = maxT;
@@ -462,7 +467,19 @@ static int plan_resident(gato_solver *s, int *groups, int *threads, int *kpw)
     if (k_per_max < 1) return 0;
     int W = (K + k_per_max - 1) / k_per_max;
     if (g > 0 && g >= W) W = g;
-    if (W > max_wg) return 0;
+    if (W > max_wg) {
+        // beyond the register file: one workgroup per CU, the knots a workgroup has no lanes for become extra rows whose
+        // matrix entries are re-read from memory every product (option pcg_semi: -1 auto, 0 never)
+        const int xt = s->plan.semi_threads;
+        if (s->pcg_semi == 0 || xt <= 0 || s->pcg_threads > 0 || s->pcg_groups > 0 || s->true_warm_start) return 0;
+        const int kp = (K + max_wg - 1) / max_wg;
+        if ((long long)(kp - xt / S) * S > (long long)s->plan.semi_rows * xt) return 0;
+        const int Wx = (K + kp - 1) / kp;
+        if (Wx < 2 || K - (Wx - 1) * kp < 1) return 0;
+        *groups = Wx; *threads = xt; *kpw = kp;
+        s->plan_semi = 1;
+        return 1;
+    }
     int k_per = (K + W - 1) / W;                     // balanced
     W = (K + k_per - 1) / k_per;
     *groups = W; *threads = t; *kpw = k_per;
@@ -521,6 +538,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.K = s->d.K; a.max_iters = max_iters; a.exit_tol = exit_tol;
         a.batch = batch;
         a.pair = s->plan_pair;
+        a.semi = cg1 ? 0 : s->plan_semi;
         // option xcd_pack: -1 = auto (default): up to 32 workgroups are placed on ONE XCD (measured 15-20 % faster hand-offs:
         // 14/7/512 f32 3.96 -> 3.11 us/iteration); spreading over 2..7 XCDs measured no better than the plain grid, so
         // auto leaves larger launches alone.  0 = off, 1..7 = force that many XCDs (tools/xcd_pack_test.py).
@@ -530,6 +548,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
             if (s->xcd_pack < 0) a.xcd_pack = need == 1 ? 1 : 0;
             else a.xcd_pack = (s->xcd_pack >= need && s->xcd_pack < 8) ? s->xcd_pack : 0;
         }
+        if (a.semi) a.xcd_pack = 0;
         a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
         a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
         // hand-off epochs: each launch gets a fresh range (two reductions per iteration plus the initial one)
@@ -551,6 +570,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.ev_stop = s->time_pcg ? s->ev_pcg1 : nullptr;
         s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT;
         s->last_variant = cg1 ? 1 : 0;
+        s->last_semi = a.semi;
         return cg1 ? s->ops->pcg_cg1(a, st) : s->ops->pcg_resident(a, st);
     }
     s->last_mode = GATO_PCG_STREAMING; s->last_groups = 0; s->last_threads = 0;

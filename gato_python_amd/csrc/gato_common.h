@@ -117,7 +117,8 @@ struct PcgLaunch {
     int xcd_pack;                // 2..32 workgroups: place them on one XCD (grid 8x oversubscribed, 7 of 8 blocks exit)
     int knots_per_wg;            // contiguous knots owned by each workgroup (last may own fewer)
     int groups;                  // W = gridDim.x
-    int threads;                 // blockDim.x (multiple of 64, >= knots_per_wg * S)
+    int threads;                 // blockDim.x (multiple of 64, >= knots_per_wg * S unless semi)
+    int semi;                    // semi-resident launch: knots_per_wg exceeds the lanes, the rest are extra rows
     unsigned long long *slots;   // hand-off granules: every 8-byte word {epoch, payload}; epochs only grow, so no re-zeroing
     unsigned epoch0;             // this launch uses epochs epoch0+1 .. (the solver hands out disjoint ranges)
     int launch_id;               // > 0; a timed-out hand-off stores it into *status (stale ids of earlier launches are ignored)
@@ -152,6 +153,8 @@ struct PcgPlan {
     int max_knots_per_wg;
     int single_max_threads;   // > max_threads: a one-workgroup variant (Pinv rows partly in LDS) exists up to this size
     int pair_threads;         // > 0: fp32 one-workgroup kernel with two rows per lane, up to this many threads
+    int semi_threads;         // > 0: semi-resident variant (extra rows re-read from memory): its workgroup size ...
+    int semi_rows;            // ... and the extra rows a lane can take
 };
 
 // Per-(dtype, S, C) kernel launchers, defined in the .hip files and instantiated for GATO_SHAPES.

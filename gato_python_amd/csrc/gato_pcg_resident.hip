@@ -77,10 +77,29 @@ __device__ __forceinline__ T row_times_window_lds(const T (&m)[3 * S - NL], cons
     return acc;
 }
 
+// Same product for a row whose 3S matrix entries are NOT register resident: they are loaded (L2 / Infinity Cache /
+// HBM) every time, all 3S loads in flight before the first FMA.  Rows handled this way are never in the system's
+// first or last block row, so no boundary entries have to be zeroed.
+template <typename T, int S, int SP>
+__device__ __forceinline__ T row_from_memory(const T *__restrict__ src, const T *xw)
+{
+    T m[3 * S];
+#pragma unroll
+    for (int c = 0; c < 3 * S; ++c) m[c] = src[(size_t)c * S];
+    return row_times_window<T, S, SP>(m, xw);
+}
+
 // NL > 0: single-workgroup variant whose Pinv rows do not fit the register budget: the last NL entries of
 // every Pinv row live in LDS (IIWA 14/7/50 in fp64: 700 rows x 84 doubles = 470 KB > the 168 VGPRs/lane that
 // 11 waves on one CU leave; 24 doubles per row = 135 KB go to LDS, the rest stays in registers).
-template <typename T, int S, int MAXT, int NL = 0, bool STAMP = false>
+// XR > 0: SEMI-resident variant for K beyond the register file: a workgroup owns more knots than it
+// has lanes for.  The first n_res-1 knots and the LAST knot of its range keep the lane = row mapping above (so the
+// boundary blocks the hand-off publishes are resident rows and nothing of the hand-off changes); the knots in between
+// are "extra" rows, up to XR per lane: their vector entries (lambda, r, p and the product just formed) live in LDS,
+// their matrix rows are re-read from memory (mostly L2 / Infinity Cache at these sizes) in every product, one row per
+// trip of a plain runtime loop (unrolling it cost registers and instruction cache and ran slower).  Still ONE persistent launch with
+// two hand-offs per iteration - against two launches per iteration of the streaming kernels.
+template <typename T, int S, int MAXT, int NL = 0, bool STAMP = false, int XR = 0>
 __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 {
     typedef ResidentCfg<T, S, MAXT> Cfg;
@@ -88,7 +107,9 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     constexpr int SP = Cfg::SP;
     constexpr int GPV = Gr::GPV;
 
-    __shared__ __attribute__((aligned(16))) T xs[2][(Cfg::MAXK + 2) * SP];   // [0] = p window, [1] = r window
+    constexpr int MAXKX = Cfg::MAXK * (1 + XR);                                // local knots incl. the extra ones
+    static_assert(NL == 0 || XR == 0, "the LDS-tail variant is single-workgroup only");
+    __shared__ __attribute__((aligned(16))) T xs[2][(MAXKX + 2) * SP];        // [0] = p window, [1] = r window
     __shared__ T wpart[2][(MAXT + 63) / 64];   // per-wave partial dots, double-buffered by epoch parity
     typedef typename VecOf<T>::type V;
     constexpr int NREG = 3 * S - NL;
@@ -117,9 +138,16 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     const int K = a.K;
     const int k0 = wg * a.knots_per_wg;
     const int nk = min(a.knots_per_wg, K - k0);
-    const int j = tid / S;                 // local knot
-    const int r_ = tid - j * S;            // row inside the knot
-    const bool active = j < nk;
+    const int jl = tid / S;                // the lane's slot
+    const int r_ = tid - jl * S;           // row inside the knot
+    const int n_res = XR > 0 ? min(nk, (int)blockDim.x / S) : nk;    // knots with lanes of their own
+    const int n_ext = nk - n_res;                                    // knots handled as extra rows (XR > 0 only)
+    const int j = (XR > 0 && n_ext > 0 && jl == n_res - 1) ? nk - 1 : jl;   // local knot: the last slot holds the LAST knot
+    const bool active = jl < n_res;
+    // extra rows of this lane: rows q = tid + e * blockDim.x (e < ne) of the knots [n_res-1, nk-1)
+    const int n_ext_rows = n_ext * S;
+    const int ne = XR > 0 ? (n_ext_rows + (int)blockDim.x - 1) / (int)blockDim.x : 0;      // workgroup-uniform trip count
+    __shared__ T xst[XR > 0 ? 4 : 1][XR > 0 ? XR * MAXT : 1];                               // [lambda | r | p | product][row]
     const int k = k0 + j;
     const bool has_left = k0 > 0;
     const bool has_right = k0 + nk < K;
@@ -156,13 +184,40 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         s_abort = 0;
         if (W == 1 && sys == 0) *a.status = 0;
     }
-    for (int i = tid; i < 2 * (Cfg::MAXK + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = (T)0;
+    for (int i = tid; i < 2 * (MAXKX + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = (T)0;
     __syncthreads();
 
     // r = gamma, lambda = 0 (gato_pcg.cuh:300-304); ghost r read straight from gamma.
     T lam = (T)0;
     T r = active ? dG[(size_t)k * S + r_] : (T)0;
     T p = (T)0, ups, rt;
+#pragma unroll 1
+    for (int e = 0; e < ne; ++e) {
+        const int q = tid + e * (int)blockDim.x;
+        if (q < n_ext_rows) {
+            const int jx = n_res - 1 + q / S, rx = q % S;
+            const T g_ = dG[(size_t)(k0 + jx) * S + rx];
+            xst[0][q] = (T)0; xst[1][q] = g_; xst[2][q] = (T)0; xst[3][q] = (T)0;
+            xs[1][(jx + 1) * SP + rx] = g_;
+        }
+    }
+    // product = M x on the extra rows (window w: 0 = p, 1 = r; x = state array xa); returns this lane's share of x . (M x)
+    auto extra_rows = [&](const T *__restrict__ M, int w, int xa) -> T {
+        T dot = (T)0;
+#pragma unroll 1
+        for (int e = 0; e < ne; ++e) {
+            const int q = tid + e * (int)blockDim.x;
+            const bool on = q < n_ext_rows;
+            const int qq = on ? q : 0;                                      // lanes without a row here read row 0
+            const int jx = n_res - 1 + qq / S, rx = qq % S;
+            const T y = row_from_memory<T, S, SP>(M + (size_t)(k0 + jx) * 3 * S * S + rx, &xs[w][jx * SP]);
+            if (on) {
+                xst[3][q] = y;
+                dot = gato::fmaT(xst[xa][q], y, dot);
+            }
+        }
+        return dot;
+    };
     if (active) xs[1][(j + 1) * SP + r_] = r;
     if (tid < S) {
         if (has_left) xs[1][tid] = dG[(size_t)(k0 - 1) * S + tid];
@@ -317,13 +372,26 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         __syncthreads();
     }
     rt = pinv_times(&xs[1][j * SP]);
-    allreduce_and_halo(rt, r * rt, eta);
+    {
+        T prod0 = r * rt;
+        if constexpr (XR > 0) prod0 += extra_rows(dP, 1, 1);
+        allreduce_and_halo(rt, prod0, eta);
+    }
     const bool rec_on = a.eta_hist != nullptr;                 // wave-uniform: one scalar branch when recording is off
     const bool rec = wg == 0 && tid == 0 && sys == 0;
     if (rec_on && rec) a.eta_hist[0] = (double)eta;
     if (!aborted) {
         p = rt;
         if (active) xs[0][(j + 1) * SP + r_] = p;
+#pragma unroll 1
+        for (int e = 0; e < ne; ++e) {
+            const int q = tid + e * (int)blockDim.x;
+            if (q < n_ext_rows) {
+                const T pn = xst[3][q];
+                xst[2][q] = pn;
+                xs[0][(n_res - 1 + q / S + 1) * SP + q % S] = pn;
+            }
+        }
         if (W > 1) {
             if (tid < S) xs[0][tid] = gh[0][tid];
             else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = gh[1][tid - S];
@@ -336,13 +404,27 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             ups = (abl & 1) ? p * sm[0] : row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
             GATO_STAMP(0)
             T v;
-            allreduce_and_halo(ups, p * ups, v);
+            {
+                T prod = p * ups;
+                if constexpr (XR > 0) prod += extra_rows(dS, 0, 2);
+                allreduce_and_halo(ups, prod, v);
+            }
             GATO_STAMP(1)
             if (aborted) break;
             const T alpha = eta / v;                                            // :364
             lam += alpha * p;                                                   // :373-377
             r -= alpha * ups;
             if (active) xs[1][(j + 1) * SP + r_] = r;
+#pragma unroll 1
+            for (int e = 0; e < ne; ++e) {
+                const int q = tid + e * (int)blockDim.x;
+                if (q < n_ext_rows) {
+                    xst[0][q] += alpha * xst[2][q];
+                    const T rn = xst[1][q] - alpha * xst[3][q];
+                    xst[1][q] = rn;
+                    xs[1][(n_res - 1 + q / S + 1) * SP + q % S] = rn;
+                }
+            }
             if (W > 1) {   // ghost r advances with the neighbours' upsilon blocks
                 if (tid < S) xs[1][tid] -= alpha * gh[0][tid];
                 else if (tid < 2 * S) xs[1][(nk + 1) * SP + (tid - S)] -= alpha * gh[1][tid - S];
@@ -352,7 +434,11 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             // r~ = Pinv r ; eta' = r . r~                                        (:380-394)
             rt = (abl & 2) ? r * pm[0] : pinv_times(&xs[1][j * SP]);
             GATO_STAMP(3)
-            allreduce_and_halo(rt, r * rt, eta_new);
+            {
+                T prod = r * rt;
+                if constexpr (XR > 0) prod += extra_rows(dP, 1, 1);
+                allreduce_and_halo(rt, prod, eta_new);
+            }
             GATO_STAMP(4)
             if (aborted) break;
             if (rec_on) {
@@ -362,6 +448,15 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             const T beta = eta_new / eta;                                       // :415
             p = rt + beta * p;                                                  // :416-419
             if (active) xs[0][(j + 1) * SP + r_] = p;
+#pragma unroll 1
+            for (int e = 0; e < ne; ++e) {
+                const int q = tid + e * (int)blockDim.x;
+                if (q < n_ext_rows) {
+                    const T pn = xst[3][q] + beta * xst[2][q];
+                    xst[2][q] = pn;
+                    xs[0][(n_res - 1 + q / S + 1) * SP + q % S] = pn;
+                }
+            }
             if (W > 1) {
                 if (tid < S) xs[0][tid] = gh[0][tid] + beta * xs[0][tid];
                 else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = gh[1][tid - S] + beta * xs[0][(nk + 1) * SP + (tid - S)];
@@ -371,6 +466,11 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         }
     }
     if (active) dL[(size_t)k * S + r_] = lam;                                   // :433-435
+#pragma unroll 1
+    for (int e = 0; e < ne; ++e) {
+        const int q = tid + e * (int)blockDim.x;
+        if (q < n_ext_rows) dL[(size_t)(k0 + n_res - 1) * S + q] = xst[0][q];
+    }
     if (wg == 0 && tid == 0) {
         a.iters[sys] = iters;
         if (a.final_eta && sys == 0) *a.final_eta = (double)eta_new;
@@ -521,6 +621,18 @@ template <> struct MaxThreads<double, 32> { static constexpr int v = 256; };
 
 }  // namespace
 
+// Semi-resident variant (XR extra rows per lane): workgroup size with room for the extra rows' registers.
+// Semi-resident variant: workgroup size by register need (resident rows 6S words + one streamed row 3S + ~80; two waves
+// per SIMD when that fits 256 registers, else one), and extra rows per lane (their four state vectors take 64 KB of LDS).
+template <typename T, int S> struct SemiThreads {
+    static constexpr int need = 9 * S * (int)(sizeof(T) / 4) + 80;
+    static constexpr int t = need <= 256 ? 512 : (need <= 512 ? 256 : 0);
+    static constexpr int v = (t > 0 && MaxThreads<T, S>::v >= t && t >= 2 * S) ? t : 0;
+};
+template <typename T, int S> struct SemiRows {
+    static constexpr int v = SemiThreads<T, S>::v > 0 ? 65536 / (4 * (int)sizeof(T) * SemiThreads<T, S>::v) : 0;
+};
+
 // Single-workgroup variants with part of the Pinv rows in LDS: (threads, NL).
 template <typename T, int S> struct SingleCu { static constexpr int threads = 0, nl = 0; };
 template <> struct SingleCu<double, 14> { static constexpr int threads = 704, nl = 24; };   // IIWA 14/7/50 fp64
@@ -532,6 +644,8 @@ int pcg_resident_plan(PcgPlan *plan)
     plan->max_knots_per_wg = MaxThreads<T, S>::v / S;
     plan->single_max_threads = SingleCu<T, S>::threads;
     plan->pair_threads = (sizeof(T) == 4 && S % 2 == 0) ? PairThreads<S>::v : 0;
+    plan->semi_threads = SemiThreads<T, S>::v;
+    plan->semi_rows = SemiRows<T, S>::v;
     return GATO_OK;
 }
 
@@ -547,6 +661,24 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
             }
             if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
             hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT>), dim3(a.batch > 1 ? a.batch : 1), dim3(a.threads), 0, st, a);
+            GATO_HIP_CHECK(hipGetLastError());
+            if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
+            return GATO_OK;
+        }
+    }
+    if constexpr (SemiThreads<T, S>::v > 0) {
+        if (a.semi) {
+            constexpr int XT = SemiThreads<T, S>::v;
+            const long long extra_rows = ((long long)a.knots_per_wg - a.threads / S) * S;
+            if (a.batch > 1 || a.lambda0 || a.threads != XT || a.groups < 2 || a.groups > 256 || a.threads / S < 2 ||
+                extra_rows > (long long)SemiRows<T, S>::v * a.threads || (long long)a.groups * a.knots_per_wg < a.K ||
+                (long long)(a.groups - 1) * a.knots_per_wg >= a.K) {
+                set_error("pcg_resident(semi): bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d)", a.K, a.groups,
+                          a.knots_per_wg, a.threads);
+                return GATO_EINVAL;
+            }
+            if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
+            hipLaunchKernelGGL((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v>), dim3(a.groups), dim3(a.threads), 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;

@@ -608,3 +608,47 @@ def test_kkt_producer_through_the_hip_path(K):
     lam_o, dz_o, it_o = o.linsys_solve(*p.csr_args(), 2, 1, K, 1e-18, 2000, p.rho, np.float64)[:3]
     assert rel(host(lam), lam_o) < 1e-8
     sol.close()
+
+
+@pytest.mark.parametrize("S,C,K,dt", [(14, 7, 14000, np.float32), (14, 7, 20011, np.float64), (32, 16, 5003, np.float32),
+                                      (12, 6, 30000, np.float32), (14, 7, 60000, np.float32)])
+def test_semi_resident_kernel_matches_the_streaming_kernels(S, C, K, dt):
+    """K beyond the register file: one persistent launch whose workgroups keep part of their knots' matrix rows in
+    registers and re-read the rest from memory every product (gato_pcg_resident.hip, XR > 0), against the streaming
+    kernels (two launches per iteration) on the same assembled system: same iterates, same exit iteration."""
+    s = system(S, C, K, 17)
+    f64 = dt == np.float64
+    res = {}
+    for semi in (-1, 0):
+        sol = make_solver(S, C, K, dt)
+        sol.set_option("pcg_semi", semi)
+        sol.set_option("record_eta", 1)
+        dev = sol.upload_system(s)
+        lam, dz = sol.new(S * K), sol.new(sol.N)
+        sol.linsys(*dev, 1e-9 if f64 else 1e-4, 40, s.rho, lam, dz)
+        sol.check_status()
+        it = int(np.frombuffer(_read_iters(sol), np.int32)[0])
+        assert sol.get_option("last_semi") == (1 if semi else 0)
+        assert sol.get_option("last_mode") == (_lib.PCG_RESIDENT if semi else _lib.PCG_STREAMING)
+        res[semi] = (host(lam).copy(), host(dz).copy(), it, sol.eta_history(min(it + 1, 40)))
+        if semi:                                              # a second solve on the same solver: fresh epochs, same bits
+            lam2, dz2 = sol.new(S * K), sol.new(sol.N)
+            sol.linsys(*dev, 1e-9 if f64 else 1e-4, 40, s.rho, lam2, dz2)
+            sol.check_status()
+            assert np.array_equal(host(lam2), res[semi][0])
+        sol.close()
+    (la, da, ia, ea), (lb, db, ib, eb) = res[-1], res[0]
+    assert abs(ia - ib) <= (0 if f64 else 1), (ia, ib)
+    n = min(len(ea), len(eb), 8)
+    assert np.allclose(ea[:n], eb[:n], rtol=1e-9 if f64 else 2e-3)
+    if ia == ib:
+        assert rel(la, lb) < (1e-10 if f64 else 5e-4) and rel(da, db) < (1e-10 if f64 else 5e-4)
+
+
+def _read_iters(sol):
+    import ctypes as ct
+    buf = (ct.c_int * 1)()
+    torch.cuda.synchronize()
+    rc = ct.CDLL("libamdhip64.so").hipMemcpy(buf, ct.c_void_p(sol.buffer_ptr(8)), 4, 2)
+    assert rc == 0
+    return bytes(buf)
