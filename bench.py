@@ -113,7 +113,7 @@ def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20):
         iters_per_s=MAX_ITERS * steps / dt_s, ms_per_step=1e3 * dt_s / steps,
         pcg_launch_ms=pcg_ms, pcg_launch_ms_min=float(np.min(ms)),
         pcg_iters_per_s=MAX_ITERS / (pcg_ms * 1e-3), pcg_us_per_iter=1e3 * pcg_ms / MAX_ITERS,
-        pcg_mode={1: "resident", 2: "streaming"}.get(sol.get_option("last_mode")),
+        pcg_mode={1: "resident", 2: "streaming"}.get(sol.get_option("last_mode")) + (" (semi)" if sol.get_option("last_semi") else ""),
         pcg_groups=sol.get_option("last_groups"), pcg_threads=sol.get_option("last_threads"),
         algorithmic_bytes_per_launch=bytes_launch,
         achieved_gbs=bytes_launch / (pcg_ms * 1e-3) / 1e9,
@@ -274,12 +274,16 @@ def main():
         # batches of independent systems: throughput mode of the K=50 shape
         sweep.append(run_batched(14, 7, 50, np.float64, 512, 10, 2, torch))
         sweep.append(run_batched(14, 7, 50, np.float32, 512, 10, 2, torch))
-        # HBM-bound regime: 20 iterations per solve keep the run short (237 us per iteration)
-        r, _ = run_single("iiwa_14_7_k131072_f32", 3, 1, torch, pcg_reps=5, max_iters=20)
-        r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
-        r["max_iters"] = 20
-        r["hbm_bytes_per_launch_pmc"] = committed_traffic("iiwa_14_7_k131072_f32")
-        sweep.append(r)
+        # HBM-bound regime (matrices 1.2 GB): 20 iterations per solve keep the run short.  Auto = the semi-resident
+        # persistent launch (one workgroup per CU, 7 % of the block rows in registers, the rest re-read every product);
+        # the streaming kernels (two launches per iteration, LDS-DMA tiles) beside it.
+        for mode, tag in ((None, ""), (2, "_streaming")):
+            r, _ = run_single("iiwa_14_7_k131072_f32", 3, 1, torch, pcg_mode=mode, pcg_reps=5, max_iters=20)
+            r["workload"] += tag
+            r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
+            r["max_iters"] = 20
+            r["hbm_bytes_per_launch_pmc"] = committed_traffic("iiwa_14_7_k131072_f32" + tag)
+            sweep.append(r)
         out["sweep"] = sweep
     print(json.dumps(out))
 

@@ -383,6 +383,8 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "last_semi")) *value = s->last_semi;
     else if (!strcmp(name, "num_cus")) *value = s->num_cus;
     else if (!strcmp(name, "batch")) *value = s->d.B;
+    else if (!strcmp(name, "max_semi_knots"))
+        *value = s->plan.semi_threads > 0 ? (s->plan.semi_threads / s->d.S + s->plan.semi_rows * s->plan.semi_threads / s->d.S) * (s->num_cus < 256 ? s->num_cus : 256) : 0;
     else if (!strcmp(name, "max_resident_knots")) *value = s->plan.max_knots_per_wg * (s->num_cus < 256 ? s->num_cus : 256);
     else { set_error("unknown option %s", name); return GATO_EINVAL; }
     return GATO_OK;
@@ -573,7 +575,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         s->last_semi = a.semi;
         return cg1 ? s->ops->pcg_cg1(a, st) : s->ops->pcg_resident(a, st);
     }
-    s->last_mode = GATO_PCG_STREAMING; s->last_groups = 0; s->last_threads = 0;
+    s->last_mode = GATO_PCG_STREAMING; s->last_groups = 0; s->last_threads = 0; s->last_semi = 0;
     s->sw.warm_start = s->true_warm_start;
     s->sw.eta_hist = (s->record_eta && max_iters <= GATO_ETA_HIST_MAX) ? s->eta_hist : nullptr;
     if (s->time_pcg) GATO_HIP_CHECK(hipEventRecord(s->ev_pcg0, st));

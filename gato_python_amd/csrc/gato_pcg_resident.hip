@@ -95,7 +95,8 @@ __device__ __forceinline__ T row_from_memory(const T *__restrict__ src, const T 
 // XR > 0: SEMI-resident variant for K beyond the register file: a workgroup owns more knots than it
 // has lanes for.  The first n_res-1 knots and the LAST knot of its range keep the lane = row mapping above (so the
 // boundary blocks the hand-off publishes are resident rows and nothing of the hand-off changes); the knots in between
-// are "extra" rows, up to XR per lane: their vector entries (lambda, r, p and the product just formed) live in LDS,
+// are "extra" rows, up to XR per lane: their r and p entries live in the LDS operand windows anyway, lambda and the
+// product just formed in two more LDS arrays,
 // their matrix rows are re-read from memory (mostly L2 / Infinity Cache at these sizes) in every product, one row per
 // trip of a plain runtime loop (unrolling it cost registers and instruction cache and ran slower).  Still ONE persistent launch with
 // two hand-offs per iteration - against two launches per iteration of the streaming kernels.
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // extra rows of this lane: rows q = tid + e * blockDim.x (e < ne) of the knots [n_res-1, nk-1)
     const int n_ext_rows = n_ext * S;
     const int ne = XR > 0 ? (n_ext_rows + (int)blockDim.x - 1) / (int)blockDim.x : 0;      // workgroup-uniform trip count
-    __shared__ T xst[XR > 0 ? 4 : 1][XR > 0 ? XR * MAXT : 1];                               // [lambda | r | p | product][row]
+    __shared__ T xst[XR > 0 ? 2 : 1][XR > 0 ? XR * MAXT : 1];                               // [lambda | product][row]; r, p: the windows
     const int k = k0 + j;
     const bool has_left = k0 > 0;
     const bool has_right = k0 + nk < K;
@@ -197,12 +198,12 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         if (q < n_ext_rows) {
             const int jx = n_res - 1 + q / S, rx = q % S;
             const T g_ = dG[(size_t)(k0 + jx) * S + rx];
-            xst[0][q] = (T)0; xst[1][q] = g_; xst[2][q] = (T)0; xst[3][q] = (T)0;
+            xst[0][q] = (T)0; xst[1][q] = (T)0;
             xs[1][(jx + 1) * SP + rx] = g_;
         }
     }
-    // product = M x on the extra rows (window w: 0 = p, 1 = r; x = state array xa); returns this lane's share of x . (M x)
-    auto extra_rows = [&](const T *__restrict__ M, int w, int xa) -> T {
+    // product = M x on the extra rows (x = window w: 0 = p, 1 = r); returns this lane's share of x . (M x)
+    auto extra_rows = [&](const T *__restrict__ M, int w) -> T {
         T dot = (T)0;
 #pragma unroll 1
         for (int e = 0; e < ne; ++e) {
@@ -212,8 +213,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             const int jx = n_res - 1 + qq / S, rx = qq % S;
             const T y = row_from_memory<T, S, SP>(M + (size_t)(k0 + jx) * 3 * S * S + rx, &xs[w][jx * SP]);
             if (on) {
-                xst[3][q] = y;
-                dot = gato::fmaT(xst[xa][q], y, dot);
+                xst[1][q] = y;
+                dot = gato::fmaT(xs[w][(jx + 1) * SP + rx], y, dot);
             }
         }
         return dot;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     rt = pinv_times(&xs[1][j * SP]);
     {
         T prod0 = r * rt;
-        if constexpr (XR > 0) prod0 += extra_rows(dP, 1, 1);
+        if constexpr (XR > 0) prod0 += extra_rows(dP, 1);
         allreduce_and_halo(rt, prod0, eta);
     }
     const bool rec_on = a.eta_hist != nullptr;                 // wave-uniform: one scalar branch when recording is off
@@ -386,11 +387,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 #pragma unroll 1
         for (int e = 0; e < ne; ++e) {
             const int q = tid + e * (int)blockDim.x;
-            if (q < n_ext_rows) {
-                const T pn = xst[3][q];
-                xst[2][q] = pn;
-                xs[0][(n_res - 1 + q / S + 1) * SP + q % S] = pn;
-            }
+            if (q < n_ext_rows) xs[0][(n_res - 1 + q / S + 1) * SP + q % S] = xst[1][q];
         }
         if (W > 1) {
             if (tid < S) xs[0][tid] = gh[0][tid];
@@ -406,7 +403,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             T v;
             {
                 T prod = p * ups;
-                if constexpr (XR > 0) prod += extra_rows(dS, 0, 2);
+                if constexpr (XR > 0) prod += extra_rows(dS, 0);
                 allreduce_and_halo(ups, prod, v);
             }
             GATO_STAMP(1)
@@ -419,10 +416,9 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             for (int e = 0; e < ne; ++e) {
                 const int q = tid + e * (int)blockDim.x;
                 if (q < n_ext_rows) {
-                    xst[0][q] += alpha * xst[2][q];
-                    const T rn = xst[1][q] - alpha * xst[3][q];
-                    xst[1][q] = rn;
-                    xs[1][(n_res - 1 + q / S + 1) * SP + q % S] = rn;
+                    const int wi = (n_res - 1 + q / S + 1) * SP + q % S;
+                    xst[0][q] += alpha * xs[0][wi];
+                    xs[1][wi] -= alpha * xst[1][q];
                 }
             }
             if (W > 1) {   // ghost r advances with the neighbours' upsilon blocks
@@ -436,7 +432,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             GATO_STAMP(3)
             {
                 T prod = r * rt;
-                if constexpr (XR > 0) prod += extra_rows(dP, 1, 1);
+                if constexpr (XR > 0) prod += extra_rows(dP, 1);
                 allreduce_and_halo(rt, prod, eta_new);
             }
             GATO_STAMP(4)
@@ -452,9 +448,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             for (int e = 0; e < ne; ++e) {
                 const int q = tid + e * (int)blockDim.x;
                 if (q < n_ext_rows) {
-                    const T pn = xst[3][q] + beta * xst[2][q];
-                    xst[2][q] = pn;
-                    xs[0][(n_res - 1 + q / S + 1) * SP + q % S] = pn;
+                    const int wi = (n_res - 1 + q / S + 1) * SP + q % S;
+                    xs[0][wi] = xst[1][q] + beta * xs[0][wi];
                 }
             }
             if (W > 1) {
@@ -629,8 +624,12 @@ template <typename T, int S> struct SemiThreads {
     static constexpr int t = need <= 256 ? 512 : (need <= 512 ? 256 : 0);
     static constexpr int v = (t > 0 && MaxThreads<T, S>::v >= t && t >= 2 * S) ? t : 0;
 };
-template <typename T, int S> struct SemiRows {
-    static constexpr int v = SemiThreads<T, S>::v > 0 ? 65536 / (4 * (int)sizeof(T) * SemiThreads<T, S>::v) : 0;
+template <typename T, int S> struct SemiRows {       // by LDS: two operand windows over all local knots + lambda and product of the extra rows
+    static constexpr int t = SemiThreads<T, S>::v;
+    static constexpr int maxk = (t + S - 1) / S, sp = pad_to(S, VecOf<T>::W), w = (int)sizeof(T);
+    static constexpr int per_row = 2 * maxk * sp * w + 2 * t * w;
+    static constexpr int fit = t > 0 ? (148 * 1024 - 2 * (maxk + 2) * sp * w) / per_row : 0;
+    static constexpr int v = fit > 32 ? 32 : fit;
 };
 
 // Single-workgroup variants with part of the Pinv rows in LDS: (threads, NL).

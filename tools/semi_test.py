@@ -26,7 +26,7 @@ def run(S, C, K, dt, semi, iters=20, reps=5):
     sol.close()
     return out, res
 
-cases = [(14, 7, 14000, np.float32), (14, 7, 16384, np.float32), (14, 7, 32768, np.float32), (14, 7, 65536, np.float32),
+cases = [(14, 7, 14000, np.float32), (14, 7, 16384, np.float32), (14, 7, 32768, np.float32), (14, 7, 65536, np.float32), (14, 7, 131072, np.float32),
          (14, 7, 16384, np.float64), (32, 16, 8192, np.float32)]
 if len(sys.argv) > 1:
     cases = cases[:int(sys.argv[1])]

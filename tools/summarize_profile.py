@@ -55,7 +55,8 @@ fetch, write = counter("fetch"), counter("write")
 # bench workloads -> (kernel template prefix, S, dtype) ; grid identifies K
 WL = {"iiwa_14_7_k50_f64": ("pcg_resident_kernel<double, 14", 50), "iiwa_14_7_k50_f32": ("pcg_single_f32x2_kernel<14", 50),
       "iiwa_14_7_k512_f32": ("pcg_resident_kernel<float, 14", 512), "iiwa_14_7_k4096_f32": ("pcg_resident_kernel<float, 14", 4096),
-      "iiwa_14_7_k4096_f64": ("pcg_resident_kernel<double, 14", 4096), "s32_c16_k1024_f32": ("pcg_resident_kernel<float, 32", 1024)}
+      "iiwa_14_7_k4096_f64": ("pcg_resident_kernel<double, 14", 4096), "s32_c16_k1024_f32": ("pcg_resident_kernel<float, 32", 1024),
+      "iiwa_14_7_k131072_f32": ("pcg_resident_kernel<float, 14", 131072)}
 bench = one(f"prof_{tag}_bench.json")
 geom = {}
 if bench:
@@ -99,7 +100,7 @@ def stream_entry(name, pick, launches_per_call, what):
 
 grids = sorted({k[1] for k in fetch if k[0].startswith("stream_step_kernel<float, 14")})
 if grids:
-    stream_entry("iiwa_14_7_k131072_f32", lambda g: g == grids[-1], 41, "20 iterations")
+    stream_entry("iiwa_14_7_k131072_f32_streaming", lambda g: g == grids[-1], 41, "20 iterations")
     if len(grids) > 1:
         stream_entry("iiwa_14_7_k512_f32_streaming", lambda g: g == grids[0], 201, "100 iterations")
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
