@@ -79,7 +79,8 @@ void *gato_solver_buffer(gato_solver *s, int which);
  * hand-off per iteration instead of two, same solution to solver tolerance, different rounding), xcd_pack (-1 auto:
  * launches of up to 32 workgroups are placed on one XCD - a placement hint, never needed for correctness; 0 off),
  * asm_mode (whole-solve entries: 0 = auto - convert + Schur + stair as ONE fused launch when K*B <= 2 x CUs, the
- * stage kernels otherwise; 1 = stage kernels; 2 = fused; both give bit-identical buffers), time_pcg (record
+ * stage kernels otherwise; 1 = stage kernels; 2 = fused; both give bit-identical buffers), pcg_semi (-1 = auto: K
+ * beyond the register file runs as one persistent semi-resident launch; 0 = the streaming kernels), time_pcg (record
  * hipEvents around the PCG launch), no_single_lds / stamp_pcg / stamp_asm / ablate (diagnostics). */
 int gato_solver_set_option(gato_solver *s, const char *name, int value);
 int gato_solver_get_option(gato_solver *s, const char *name, int *value);
