@@ -473,7 +473,7 @@ static int plan_resident(gato_solver *s, int *groups, int *threads, int *kpw)
         // beyond the register file: one workgroup per CU, the knots a workgroup has no lanes for become extra rows whose
         // matrix entries are re-read from memory every product (option pcg_semi: -1 auto, 0 never)
         const int xt = s->plan.semi_threads;
-        if (s->pcg_semi == 0 || xt <= 0 || s->pcg_threads > 0 || s->pcg_groups > 0 || s->true_warm_start) return 0;
+        if (s->pcg_semi == 0 || xt <= 0 || s->pcg_threads > 0 || s->pcg_groups > 0) return 0;
         const int kp = (K + max_wg - 1) / max_wg;
         if ((long long)(kp - xt / S) * S > (long long)s->plan.semi_rows * xt) return 0;
         const int Wx = (K + kp - 1) / kp;

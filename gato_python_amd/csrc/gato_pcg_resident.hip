@@ -352,6 +352,15 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         const T *__restrict__ dL0 = static_cast<const T *>(a.lambda0) + sys * S * K;
         lam = active ? dL0[(size_t)k * S + r_] : (T)0;
         if (active) xs[0][(j + 1) * SP + r_] = lam;
+#pragma unroll 1
+        for (int e = 0; e < ne; ++e) {
+            const int q = tid + e * (int)blockDim.x;
+            if (q < n_ext_rows) {
+                const T l0 = dL0[(size_t)(k0 + n_res - 1) * S + q];
+                xst[0][q] = l0;
+                xs[0][(n_res - 1 + q / S + 1) * SP + q % S] = l0;
+            }
+        }
         if (tid < S) {
             if (has_left) xs[0][tid] = dL0[(size_t)(k0 - 1) * S + tid];
         } else if (tid < 2 * S) {
@@ -359,8 +368,14 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         }
         __syncthreads();
         r -= row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
+        if constexpr (XR > 0) (void)extra_rows(dS, 0);                       // product array <- S lambda0 on the extra rows
         __syncthreads();
         if (active) xs[1][(j + 1) * SP + r_] = r;
+#pragma unroll 1
+        for (int e = 0; e < ne; ++e) {
+            const int q = tid + e * (int)blockDim.x;
+            if (q < n_ext_rows) xs[1][(n_res - 1 + q / S + 1) * SP + q % S] -= xst[1][q];
+        }
         if (W > 1) {
             T dummy;
             allreduce_and_halo(r, (T)0, dummy);
@@ -669,7 +684,7 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
         if (a.semi) {
             constexpr int XT = SemiThreads<T, S>::v;
             const long long extra_rows = ((long long)a.knots_per_wg - a.threads / S) * S;
-            if (a.batch > 1 || a.lambda0 || a.threads != XT || a.groups < 2 || a.groups > 256 || a.threads / S < 2 ||
+            if (a.batch > 1 || a.threads != XT || a.groups < 2 || a.groups > 256 || a.threads / S < 2 ||
                 extra_rows > (long long)SemiRows<T, S>::v * a.threads || (long long)a.groups * a.knots_per_wg < a.K ||
                 (long long)(a.groups - 1) * a.knots_per_wg >= a.K) {
                 set_error("pcg_resident(semi): bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d)", a.K, a.groups,

@@ -298,7 +298,8 @@ print('Test passed')
 @pytest.mark.parametrize("S,C,K,dt,opts", [(14, 7, 50, np.float64, {}), (14, 7, 50, np.float32, {}),
                                            (14, 7, 300, np.float64, {}), (2, 1, 40, np.float64, dict(pcg_threads=64)),
                                            (14, 7, 300, np.float64, dict(pcg_mode=_lib.PCG_STREAMING)),
-                                           (32, 16, 40, np.float32, dict(pcg_mode=_lib.PCG_STREAMING))])
+                                           (32, 16, 40, np.float32, dict(pcg_mode=_lib.PCG_STREAMING)),
+                                           (14, 7, 14500, np.float64, {})])                 # semi-resident launch
 def test_true_warm_start(S, C, K, dt, opts):
     """opt-in real warm start r0 = gamma - S lambda0 (the default stays the reference's
     no-op, D5).  Checked against the numpy restatement with the same lambda0."""
