@@ -40,8 +40,10 @@ WORKLOADS = {
     "iiwa_14_7_k4096_f32": (14, 7, 4096, np.float32, "configs[3] on one GPU"),
     "iiwa_14_7_k4096_f64": (14, 7, 4096, np.float64, "configs[3] on one GPU, fp64"),
     "s32_c16_k1024_f32": (32, 16, 1024, np.float32, "configs[4]"),
-    # beyond register residency: the streaming kernel, genuinely HBM-bound (matrices 1.2 GB > 256 MB Infinity Cache)
-    "iiwa_14_7_k131072_f32": (14, 7, 131072, np.float32, "K beyond residency, streaming kernel (HBM-roofline run)"),
+    # beyond register residency: semi-resident persistent launch / streaming kernels
+    "iiwa_14_7_k16384_f32": (14, 7, 16384, np.float32, "K just beyond the register file (matrices 77 MB: L2 / Infinity Cache)"),
+    # genuinely HBM-bound: matrices 1.2 GB > 256 MB Infinity Cache
+    "iiwa_14_7_k131072_f32": (14, 7, 131072, np.float32, "K far beyond residency (HBM-roofline run)"),
 }
 MAX_ITERS = 100
 PCG_VARIANT = 0     # 1 = opt-in single-reduction (Chronopoulos-Gear) resident kernel, sweep entries only
@@ -274,6 +276,9 @@ def main():
         # batches of independent systems: throughput mode of the K=50 shape
         sweep.append(run_batched(14, 7, 50, np.float64, 512, 10, 2, torch))
         sweep.append(run_batched(14, 7, 50, np.float32, 512, 10, 2, torch))
+        r, _ = run_single("iiwa_14_7_k16384_f32", 5, 2, torch, pcg_reps=5)
+        r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
+        sweep.append(r)
         # HBM-bound regime (matrices 1.2 GB): 20 iterations per solve keep the run short.  Auto = the semi-resident
         # persistent launch (one workgroup per CU, 7 % of the block rows in registers, the rest re-read every product);
         # the streaming kernels (two launches per iteration, LDS-DMA tiles) beside it.
