@@ -12,7 +12,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 bad = 0
 for (S, C, K, dt, opts) in [(14, 7, 512, np.float32, {}), (14, 7, 4096, np.float32, {}), (14, 7, 4096, np.float64, {}),
                             (32, 16, 1024, np.float32, {}), (14, 7, 4096, np.float32, dict(pcg_variant=1)),
-                            (14, 7, 700, np.float64, dict(pcg_threads=256)), (14, 7, 50, np.float64, {})]:
+                            (14, 7, 700, np.float64, dict(pcg_threads=256)), (14, 7, 50, np.float64, {}),
+                            (14, 7, 20000, np.float32, {}), (14, 7, 15000, np.float64, {})]:     # semi-resident launches
     s = synth.make_system(S, C, K, seed=3)
     sol = Solver(S, C, K, dt)
     for k_, v in opts.items():
