@@ -37,7 +37,12 @@ if trace:
     with open(os.path.join(out, f"{tag}_pcg_launches.csv"), "w") as f:
         f.write("kernel,grid_threads,workgroup_threads,launches,avg_ns,min_ns,max_ns\n")
         for k, v in sorted(launch.items()):
-            f.write(f'"{k[0]}",{k[1]},{k[2]},{len(v)},{sum(v) / len(v):.0f},{min(v)},{max(v)}\n')
+            groups = [v]
+            if max(v) > 1.6 * min(v) and k[0].endswith(", 16>"):      # two bench workloads on one (kernel, grid): split by duration
+                cut = (max(v) + min(v)) / 2
+                groups = [[x for x in v if x < cut], [x for x in v if x >= cut]]
+            for g in groups:
+                f.write(f'"{k[0]}",{k[1]},{k[2]},{len(g)},{sum(g) / len(g):.0f},{min(g)},{max(g)}\n')
 
 
 def counter(kind):
@@ -69,17 +74,28 @@ if bench:
     except Exception as e:
         print("bench json unreadable:", e)
 traffic = {}
+# the semi-resident launches of K = 16384 and K = 131072 share kernel and grid (256 x 512): told apart by their traffic
+WL["iiwa_14_7_k16384_f32"] = ("pcg_resident_kernel<float, 14", 16384)
+
+
 for name, (prefix, K) in WL.items():
     for key in fetch:
         if key[0].startswith(prefix) and geom.get(name) == key[1]:
-            f_kb = sum(fetch[key]) / len(fetch[key])
-            w_kb = sum(write[key]) / len(write[key]) if key in write else 0.0
+            fv, wv = fetch[key], write.get(key, [])
+            if key[0].endswith(", 16>") and ("iiwa_14_7_k16384_f32" in geom and "iiwa_14_7_k131072_f32" in geom):
+                big = name == "iiwa_14_7_k131072_f32"
+                fv = [v for v in fv if (v >= max(fetch[key]) / 2) == big]
+                wv = [v for v in wv if (v >= max(write[key]) / 2) == big] if wv else wv
+            if not fv:
+                continue
+            f_kb = sum(fv) / len(fv)
+            w_kb = sum(wv) / len(wv) if wv else 0.0
             traffic[name] = dict(kernel=key[0], grid_threads=key[1], fetch_size_kb=f_kb, write_size_kb=w_kb,
                                  hbm_bytes_per_launch=(2 * f_kb + w_kb) * 1024,
                                  note="HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB: gfx950 FETCH_SIZE reports half the "
                                       "fetched bytes (MI355X_MICROARCH.md, HBM section); calibrated here on the K=50 "
                                       "launches, where 2 x FETCH_SIZE equals the S + Pinv bytes read once. launches=%d"
-                                      % len(fetch[key]))
+                                      % len(fv))
 # streaming PCG: traffic of one whole gato_pcg call = sum over its launches (init + 2 per iteration).  Two bench
 # entries stream: K = 131072 (20 iterations, 41 launches, the largest grid) and K = 512 (100 iterations, 201 launches)
 def stream_entry(name, pick, launches_per_call, what):
