@@ -472,14 +472,21 @@ static int plan_resident(gato_solver *s, int *groups, int *threads, int *kpw)
     if (W > max_wg) {
         // beyond the register file: one workgroup per CU, the knots a workgroup has no lanes for become extra rows whose
         // matrix entries are re-read from memory every product (option pcg_semi: -1 auto, 0 never)
-        const int xt = s->plan.semi_threads;
-        if (s->pcg_semi == 0 || xt <= 0 || s->pcg_threads > 0 || s->pcg_groups > 0) return 0;
+        // option pcg_semi: -1 auto, 0 never (streaming kernels), 1 semi-resident, 2 no resident rows
+        if (s->pcg_semi == 0 || s->pcg_threads > 0 || s->pcg_groups > 0) return 0;
         const int kp = (K + max_wg - 1) / max_wg;
-        if ((long long)(kp - xt / S) * S > (long long)s->plan.semi_rows * xt) return 0;
         const int Wx = (K + kp - 1) / kp;
-        if (Wx < 2 || K - (Wx - 1) * kp < 1) return 0;
-        *groups = Wx; *threads = xt; *kpw = kp;
-        s->plan_semi = 1;
+        if (Wx < 2) return 0;
+        const int xt = s->plan.semi_threads, nt = s->plan.nores_threads;
+        const bool semi_ok = xt > 0 && (long long)(kp - xt / S) * S <= (long long)s->plan.semi_rows * xt;
+        const bool nores_ok = nt > 0 && (long long)kp * S <= (long long)s->plan.nores_rows * nt;
+        int which = 0;
+        if (s->pcg_semi == 1) which = semi_ok ? 1 : 0;
+        else if (s->pcg_semi == 2) which = nores_ok ? 2 : 0;
+        else which = semi_ok ? 1 : (nores_ok ? 2 : 0);
+        if (!which) return 0;
+        *groups = Wx; *threads = which == 1 ? xt : nt; *kpw = kp;
+        s->plan_semi = which;
         return 1;
     }
     int k_per = (K + W - 1) / W;                     // balanced

@@ -118,7 +118,7 @@ struct PcgLaunch {
     int knots_per_wg;            // contiguous knots owned by each workgroup (last may own fewer)
     int groups;                  // W = gridDim.x
     int threads;                 // blockDim.x (multiple of 64, >= knots_per_wg * S unless semi)
-    int semi;                    // semi-resident launch: knots_per_wg exceeds the lanes, the rest are extra rows
+    int semi;                    // 1: semi-resident launch (knots_per_wg exceeds the lanes, the rest are extra rows); 2: no resident rows
     unsigned long long *slots;   // hand-off granules: every 8-byte word {epoch, payload}; epochs only grow, so no re-zeroing
     unsigned epoch0;             // this launch uses epochs epoch0+1 .. (the solver hands out disjoint ranges)
     int launch_id;               // > 0; a timed-out hand-off stores it into *status (stale ids of earlier launches are ignored)
@@ -155,6 +155,8 @@ struct PcgPlan {
     int pair_threads;         // > 0: fp32 one-workgroup kernel with two rows per lane, up to this many threads
     int semi_threads;         // > 0: semi-resident variant (extra rows re-read from memory): its workgroup size ...
     int semi_rows;            // ... and the extra rows a lane can take
+    int nores_threads;        // > 0: variant without resident rows: workgroup size ...
+    int nores_rows;           // ... and rows per lane
 };
 
 // Per-(dtype, S, C) kernel launchers, defined in the .hip files and instantiated for GATO_SHAPES.

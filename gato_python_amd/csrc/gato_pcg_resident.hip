@@ -81,11 +81,17 @@ __device__ __forceinline__ T row_times_window_lds(const T (&m)[3 * S - NL], cons
 // HBM) every time, all 3S loads in flight before the first FMA.  Rows handled this way are never in the system's
 // first or last block row, so no boundary entries have to be zeroed.
 template <typename T, int S, int SP>
-__device__ __forceinline__ T row_from_memory(const T *__restrict__ src, const T *xw)
+__device__ __forceinline__ T row_from_memory(const T *__restrict__ src, const T *xw, bool no_left = false, bool no_right = false)
 {
     T m[3 * S];
 #pragma unroll
     for (int c = 0; c < 3 * S; ++c) m[c] = src[(size_t)c * S];
+    // first / last block row of the system: the left / right block is not part of the matrix (never written) - drop it
+#pragma unroll
+    for (int c = 0; c < S; ++c) {
+        if (no_left) m[c] = (T)0;
+        if (no_right) m[2 * S + c] = (T)0;
+    }
     return row_times_window<T, S, SP>(m, xw);
 }
 
@@ -100,7 +106,11 @@ __device__ __forceinline__ T row_from_memory(const T *__restrict__ src, const T 
 // their matrix rows are re-read from memory (mostly L2 / Infinity Cache at these sizes) in every product, one row per
 // trip of a plain runtime loop (unrolling it cost registers and instruction cache and ran slower).  Still ONE persistent launch with
 // two hand-offs per iteration - against two launches per iteration of the streaming kernels.
-template <typename T, int S, int MAXT, int NL = 0, bool STAMP = false, int XR = 0>
+// NR (with XR > 0): NO resident rows at all - every row of the workgroup's range is an "extra" row.  Without the 6S
+// matrix registers per lane the workgroup can be 2-4x larger (more loads in flight per CU): the variant for shapes whose
+// resident rows leave one wave per SIMD (fp64, S = 32) and for the HBM-bound end of the range.  The boundary blocks the
+// hand-off publishes are then read from the product array in LDS instead of from lane registers.
+template <typename T, int S, int MAXT, int NL = 0, bool STAMP = false, int XR = 0, bool NR = false>
 __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 {
     typedef ResidentCfg<T, S, MAXT> Cfg;
@@ -108,8 +118,9 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     constexpr int SP = Cfg::SP;
     constexpr int GPV = Gr::GPV;
 
-    constexpr int MAXKX = Cfg::MAXK * (1 + XR);                                // local knots incl. the extra ones
+    constexpr int MAXKX = NR ? Cfg::MAXK * XR : Cfg::MAXK * (1 + XR);          // local knots incl. the extra ones
     static_assert(NL == 0 || XR == 0, "the LDS-tail variant is single-workgroup only");
+    static_assert(!NR || (XR > 0 && 2 * S <= 64), "NR: every row is an extra row; wave 0 publishes both boundary blocks");
     __shared__ __attribute__((aligned(16))) T xs[2][(MAXKX + 2) * SP];        // [0] = p window, [1] = r window
     __shared__ T wpart[2][(MAXT + 63) / 64];   // per-wave partial dots, double-buffered by epoch parity
     typedef typename VecOf<T>::type V;
@@ -141,11 +152,12 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     const int nk = min(a.knots_per_wg, K - k0);
     const int jl = tid / S;                // the lane's slot
     const int r_ = tid - jl * S;           // row inside the knot
-    const int n_res = XR > 0 ? min(nk, (int)blockDim.x / S) : nk;    // knots with lanes of their own
+    const int n_res = NR ? 0 : (XR > 0 ? min(nk, (int)blockDim.x / S) : nk);    // knots with lanes of their own
     const int n_ext = nk - n_res;                                    // knots handled as extra rows (XR > 0 only)
-    const int j = (XR > 0 && n_ext > 0 && jl == n_res - 1) ? nk - 1 : jl;   // local knot: the last slot holds the LAST knot
+    const int j = (XR > 0 && !NR && n_ext > 0 && jl == n_res - 1) ? nk - 1 : jl;   // local knot: the last slot holds the LAST knot
     const bool active = jl < n_res;
-    // extra rows of this lane: rows q = tid + e * blockDim.x (e < ne) of the knots [n_res-1, nk-1)
+    const int xk = NR ? 0 : n_res - 1;                               // first local knot of the extra rows
+    // extra rows of this lane: rows q = tid + e * blockDim.x (e < ne) of the knots [xk, xk + n_ext)
     const int n_ext_rows = n_ext * S;
     const int ne = XR > 0 ? (n_ext_rows + (int)blockDim.x - 1) / (int)blockDim.x : 0;      // workgroup-uniform trip count
     __shared__ T xst[XR > 0 ? 2 : 1][XR > 0 ? XR * MAXT : 1];                               // [lambda | product][row]; r, p: the windows
@@ -162,8 +174,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // bd layout: block-row k = [left|main|right], each S*S column-major -> element (r, c) of the
     // S x 3S strip sits at c*S + r (gato_utils.cuh:53-54,97-98).  First/last block rows have no
     // left/right block (gato_utils.cuh:157-174): those entries are forced to zero here.
-    T sm[3 * S], pm[NREG];
-    {
+    T sm[NR ? 1 : 3 * S], pm[NR ? 1 : NREG];
+    if constexpr (!NR) {
         const size_t base = (size_t)(active ? k : 0) * 3 * S * S + r_;
 #pragma unroll
         for (int c = 0; c < 3 * S; ++c) {
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     for (int e = 0; e < ne; ++e) {
         const int q = tid + e * (int)blockDim.x;
         if (q < n_ext_rows) {
-            const int jx = n_res - 1 + q / S, rx = q % S;
+            const int jx = xk + q / S, rx = q % S;
             const T g_ = dG[(size_t)(k0 + jx) * S + rx];
             xst[0][q] = (T)0; xst[1][q] = (T)0;
             xs[1][(jx + 1) * SP + rx] = g_;
@@ -210,8 +222,9 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             const int q = tid + e * (int)blockDim.x;
             const bool on = q < n_ext_rows;
             const int qq = on ? q : 0;                                      // lanes without a row here read row 0
-            const int jx = n_res - 1 + qq / S, rx = qq % S;
-            const T y = row_from_memory<T, S, SP>(M + (size_t)(k0 + jx) * 3 * S * S + rx, &xs[w][jx * SP]);
+            const int jx = xk + qq / S, rx = qq % S;
+            const T y = row_from_memory<T, S, SP>(M + (size_t)(k0 + jx) * 3 * S * S + rx, &xs[w][jx * SP],
+                                                  NR && k0 + jx == 0, NR && k0 + jx == K - 1);
             if (on) {
                 xst[1][q] = y;
                 dot = gato::fmaT(xs[w][(jx + 1) * SP + rx], y, dot);
@@ -250,11 +263,17 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         T *wp = wpart[epoch & 1];
         if (lane == 0) wp[wave] = ws;
         gu64 *mine = slots + ((size_t)(epoch & 1) * W + wg) * slotG;
-        if (W > 1 && active) {
+        if (!NR && W > 1 && active) {
             if (j == 0) Gr::store(mine + 16 + r_ * GPV, epoch, val);
             if (j == nk - 1) Gr::store(mine + 16 + (S + r_) * GPV, epoch, val);
         }
         __syncthreads();                                                       // B1
+        if constexpr (NR) {                 // boundary blocks of the vector just formed: from the product array (complete after B1)
+            if (W > 1) {
+                if (tid < S) Gr::store(mine + 16 + tid * GPV, epoch, xst[1][tid]);
+                else if (tid < 2 * S) Gr::store(mine + 16 + tid * GPV, epoch, xst[1][(nk - 1) * S + (tid - S)]);
+            }
+        }
         if (W == 1) {
             // one workgroup: every wave sums the per-wave partials itself (fixed order), no second barrier
             // (one LDS read per lane + a DPP sum: a serial loop over the partials would pay one LDS
@@ -342,7 +361,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 
     // ---- r~ = Pinv r ; p = r~ ; eta = r . r~   (gato_pcg.cuh:316-335) ------------------------
     auto pinv_times = [&](const T *xw) -> T {
-        if constexpr (NL > 0) return row_times_window_lds<T, S, SP, NL, MAXT>(pm, ptail, tid, xw);
+        if constexpr (NR) return (T)0;
+        else if constexpr (NL > 0) return row_times_window_lds<T, S, SP, NL, MAXT>(pm, ptail, tid, xw);
         else return row_times_window<T, S, SP>(pm, xw);
     };
     // ---- optional true warm start (the reference accepts input_lambda but restarts from
@@ -356,9 +376,9 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         for (int e = 0; e < ne; ++e) {
             const int q = tid + e * (int)blockDim.x;
             if (q < n_ext_rows) {
-                const T l0 = dL0[(size_t)(k0 + n_res - 1) * S + q];
+                const T l0 = dL0[(size_t)(k0 + xk) * S + q];
                 xst[0][q] = l0;
-                xs[0][(n_res - 1 + q / S + 1) * SP + q % S] = l0;
+                xs[0][(xk + q / S + 1) * SP + q % S] = l0;
             }
         }
         if (tid < S) {
@@ -367,14 +387,19 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             if (has_right) xs[0][(nk + 1) * SP + (tid - S)] = dL0[(size_t)(k0 + nk) * S + (tid - S)];
         }
         __syncthreads();
-        r -= row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
+        if constexpr (!NR) r -= row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
         if constexpr (XR > 0) (void)extra_rows(dS, 0);                       // product array <- S lambda0 on the extra rows
         __syncthreads();
         if (active) xs[1][(j + 1) * SP + r_] = r;
 #pragma unroll 1
         for (int e = 0; e < ne; ++e) {
             const int q = tid + e * (int)blockDim.x;
-            if (q < n_ext_rows) xs[1][(n_res - 1 + q / S + 1) * SP + q % S] -= xst[1][q];
+            if (q < n_ext_rows) xs[1][(xk + q / S + 1) * SP + q % S] -= xst[1][q];
+        }
+        if constexpr (NR) {                 // the hand-off publishes from the product array: put r's boundary blocks there
+            __syncthreads();
+            if (tid < S) xst[1][tid] = xs[1][SP + tid];
+            else if (tid < 2 * S) xst[1][(nk - 1) * S + (tid - S)] = xs[1][nk * SP + (tid - S)];
         }
         if (W > 1) {
             T dummy;
@@ -402,7 +427,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 #pragma unroll 1
         for (int e = 0; e < ne; ++e) {
             const int q = tid + e * (int)blockDim.x;
-            if (q < n_ext_rows) xs[0][(n_res - 1 + q / S + 1) * SP + q % S] = xst[1][q];
+            if (q < n_ext_rows) xs[0][(xk + q / S + 1) * SP + q % S] = xst[1][q];
         }
         if (W > 1) {
             if (tid < S) xs[0][tid] = gh[0][tid];
@@ -413,7 +438,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         for (int it = 0; it < a.max_iters; ++it) {                              // gato_pcg.cuh:348
             // upsilon = S p ; v = p . upsilon                                     (:349-357)
             GATO_STAMP(5)
-            ups = (abl & 1) ? p * sm[0] : row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
+            if constexpr (NR) ups = (T)0;
+            else ups = (abl & 1) ? p * sm[0] : row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
             GATO_STAMP(0)
             T v;
             {
@@ -431,7 +457,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             for (int e = 0; e < ne; ++e) {
                 const int q = tid + e * (int)blockDim.x;
                 if (q < n_ext_rows) {
-                    const int wi = (n_res - 1 + q / S + 1) * SP + q % S;
+                    const int wi = (xk + q / S + 1) * SP + q % S;
                     xst[0][q] += alpha * xs[0][wi];
                     xs[1][wi] -= alpha * xst[1][q];
                 }
@@ -463,7 +489,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             for (int e = 0; e < ne; ++e) {
                 const int q = tid + e * (int)blockDim.x;
                 if (q < n_ext_rows) {
-                    const int wi = (n_res - 1 + q / S + 1) * SP + q % S;
+                    const int wi = (xk + q / S + 1) * SP + q % S;
                     xs[0][wi] = xst[1][q] + beta * xs[0][wi];
                 }
             }
@@ -479,7 +505,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 #pragma unroll 1
     for (int e = 0; e < ne; ++e) {
         const int q = tid + e * (int)blockDim.x;
-        if (q < n_ext_rows) dL[(size_t)(k0 + n_res - 1) * S + q] = xst[0][q];
+        if (q < n_ext_rows) dL[(size_t)(k0 + xk) * S + q] = xst[0][q];
     }
     if (wg == 0 && tid == 0) {
         a.iters[sys] = iters;
@@ -647,6 +673,19 @@ template <typename T, int S> struct SemiRows {       // by LDS: two operand wind
     static constexpr int v = fit > 32 ? 32 : fit;
 };
 
+// No-resident-rows variant (NR): workgroup size by the registers one streamed row needs, rows per lane by LDS.
+template <typename T, int S> struct NoresThreads {
+    static constexpr int need = 4 * S * (int)(sizeof(T) / 4) + 70;
+    static constexpr int v = 2 * S > 64 ? 0 : (need <= 120 ? 1024 : need <= 160 ? 768 : need <= 250 ? 512 : 256);
+};
+template <typename T, int S> struct NoresRows {
+    static constexpr int t = NoresThreads<T, S>::v;
+    static constexpr int maxk = t > 0 ? (t + S - 1) / S : 1, sp = pad_to(S, VecOf<T>::W), w = (int)sizeof(T);
+    static constexpr int per_row = 2 * maxk * sp * w + 2 * t * w;
+    static constexpr int fit = t > 0 ? (148 * 1024 - 4 * sp * w) / per_row : 0;
+    static constexpr int v = fit > 32 ? 32 : fit;
+};
+
 // Single-workgroup variants with part of the Pinv rows in LDS: (threads, NL).
 template <typename T, int S> struct SingleCu { static constexpr int threads = 0, nl = 0; };
 template <> struct SingleCu<double, 14> { static constexpr int threads = 704, nl = 24; };   // IIWA 14/7/50 fp64
@@ -660,6 +699,8 @@ int pcg_resident_plan(PcgPlan *plan)
     plan->pair_threads = (sizeof(T) == 4 && S % 2 == 0) ? PairThreads<S>::v : 0;
     plan->semi_threads = SemiThreads<T, S>::v;
     plan->semi_rows = SemiRows<T, S>::v;
+    plan->nores_threads = NoresThreads<T, S>::v;
+    plan->nores_rows = NoresRows<T, S>::v;
     return GATO_OK;
 }
 
@@ -681,7 +722,7 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
         }
     }
     if constexpr (SemiThreads<T, S>::v > 0) {
-        if (a.semi) {
+        if (a.semi == 1) {
             constexpr int XT = SemiThreads<T, S>::v;
             const long long extra_rows = ((long long)a.knots_per_wg - a.threads / S) * S;
             if (a.batch > 1 || a.threads != XT || a.groups < 2 || a.groups > 256 || a.threads / S < 2 ||
@@ -693,6 +734,23 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
             }
             if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
             hipLaunchKernelGGL((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v>), dim3(a.groups), dim3(a.threads), 0, st, a);
+            GATO_HIP_CHECK(hipGetLastError());
+            if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
+            return GATO_OK;
+        }
+    }
+    if constexpr (NoresThreads<T, S>::v > 0) {
+        if (a.semi == 2) {
+            constexpr int NT = NoresThreads<T, S>::v, NX = NoresRows<T, S>::v;
+            if (a.batch > 1 || a.threads != NT || a.groups < 2 || a.groups > 256 ||
+                (long long)a.knots_per_wg * S > (long long)NX * NT || (long long)a.groups * a.knots_per_wg < a.K ||
+                (long long)(a.groups - 1) * a.knots_per_wg >= a.K) {
+                set_error("pcg_resident(no resident rows): bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d)", a.K,
+                          a.groups, a.knots_per_wg, a.threads);
+                return GATO_EINVAL;
+            }
+            if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
+            hipLaunchKernelGGL((pcg_resident_kernel<T, S, NT, 0, false, NX, true>), dim3(a.groups), dim3(a.threads), 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;

@@ -299,7 +299,8 @@ print('Test passed')
                                            (14, 7, 300, np.float64, {}), (2, 1, 40, np.float64, dict(pcg_threads=64)),
                                            (14, 7, 300, np.float64, dict(pcg_mode=_lib.PCG_STREAMING)),
                                            (32, 16, 40, np.float32, dict(pcg_mode=_lib.PCG_STREAMING)),
-                                           (14, 7, 14500, np.float64, {})])                 # semi-resident launch
+                                           (14, 7, 14500, np.float64, {}),                  # semi-resident launch
+                                           (14, 7, 14500, np.float64, dict(pcg_semi=2))])   # ... without resident rows
 def test_true_warm_start(S, C, K, dt, opts):
     """opt-in real warm start r0 = gamma - S lambda0 (the default stays the reference's
     no-op, D5).  Checked against the numpy restatement with the same lambda0."""
@@ -611,16 +612,19 @@ def test_kkt_producer_through_the_hip_path(K):
     sol.close()
 
 
-@pytest.mark.parametrize("S,C,K,dt", [(14, 7, 14000, np.float32), (14, 7, 20011, np.float64), (32, 16, 5003, np.float32),
-                                      (12, 6, 30000, np.float32), (14, 7, 60000, np.float32)])
-def test_semi_resident_kernel_matches_the_streaming_kernels(S, C, K, dt):
+@pytest.mark.parametrize("S,C,K,dt,which", [(14, 7, 14000, np.float32, 1), (14, 7, 20011, np.float64, 1), (32, 16, 5003, np.float32, 1),
+                                            (12, 6, 30000, np.float32, 1), (14, 7, 60000, np.float32, 1),
+                                            (14, 7, 14000, np.float32, 2), (14, 7, 20011, np.float64, 2), (32, 16, 3001, np.float64, 2),
+                                            (2, 1, 140000, np.float32, 2)])
+def test_semi_resident_kernel_matches_the_streaming_kernels(S, C, K, dt, which):
     """K beyond the register file: one persistent launch whose workgroups keep part of their knots' matrix rows in
     registers and re-read the rest from memory every product (gato_pcg_resident.hip, XR > 0), against the streaming
-    kernels (two launches per iteration) on the same assembled system: same iterates, same exit iteration."""
+    kernels (two launches per iteration) on the same assembled system: same iterates, same exit iteration.
+    which = 1: boundary and leading knots register-resident; 2: the variant without resident rows (what fp64 at S = 32 gets)."""
     s = system(S, C, K, 17)
     f64 = dt == np.float64
     res = {}
-    for semi in (-1, 0):
+    for semi in (which, 0):
         sol = make_solver(S, C, K, dt)
         sol.set_option("pcg_semi", semi)
         sol.set_option("record_eta", 1)
@@ -629,7 +633,7 @@ def test_semi_resident_kernel_matches_the_streaming_kernels(S, C, K, dt):
         sol.linsys(*dev, 1e-9 if f64 else 1e-4, 40, s.rho, lam, dz)
         sol.check_status()
         it = int(np.frombuffer(_read_iters(sol), np.int32)[0])
-        assert sol.get_option("last_semi") == (1 if semi else 0)
+        assert sol.get_option("last_semi") == semi
         assert sol.get_option("last_mode") == (_lib.PCG_RESIDENT if semi else _lib.PCG_STREAMING)
         res[semi] = (host(lam).copy(), host(dz).copy(), it, sol.eta_history(min(it + 1, 40)))
         if semi:                                              # a second solve on the same solver: fresh epochs, same bits
@@ -638,7 +642,7 @@ def test_semi_resident_kernel_matches_the_streaming_kernels(S, C, K, dt):
             sol.check_status()
             assert np.array_equal(host(lam2), res[semi][0])
         sol.close()
-    (la, da, ia, ea), (lb, db, ib, eb) = res[-1], res[0]
+    (la, da, ia, ea), (lb, db, ib, eb) = res[which], res[0]
     assert abs(ia - ib) <= (0 if f64 else 1), (ia, ib)
     n = min(len(ea), len(eb), 8)
     assert np.allclose(ea[:n], eb[:n], rtol=1e-9 if f64 else 2e-3)
