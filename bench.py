@@ -278,6 +278,7 @@ def main():
         sweep.append(run_batched(14, 7, 50, np.float32, 512, 10, 2, torch))
         r, _ = run_single("iiwa_14_7_k16384_f32", 5, 2, torch, pcg_reps=5)
         r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
+        r["hbm_bytes_per_launch_pmc"] = committed_traffic("iiwa_14_7_k16384_f32")
         sweep.append(r)
         # HBM-bound regime (matrices 1.2 GB): 20 iterations per solve keep the run short.  Auto = the semi-resident
         # persistent launch (one workgroup per CU, 7 % of the block rows in registers, the rest re-read every product);

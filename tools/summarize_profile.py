@@ -80,7 +80,7 @@ WL["iiwa_14_7_k16384_f32"] = ("pcg_resident_kernel<float, 14", 16384)
 
 for name, (prefix, K) in WL.items():
     for key in fetch:
-        if key[0].startswith(prefix) and geom.get(name) == key[1]:
+        if key[0].startswith(prefix) and geom.get(name) in (key[1], key[1] // 8 if key[1] % 8 == 0 else -1):   # xcd_pack launches an 8x grid
             fv, wv = fetch[key], write.get(key, [])
             if key[0].endswith(", 16>") and ("iiwa_14_7_k16384_f32" in geom and "iiwa_14_7_k131072_f32" in geom):
                 big = name == "iiwa_14_7_k131072_f32"
