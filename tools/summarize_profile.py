@@ -38,7 +38,7 @@ if trace:
         f.write("kernel,grid_threads,workgroup_threads,launches,avg_ns,min_ns,max_ns\n")
         for k, v in sorted(launch.items()):
             groups = [v]
-            if max(v) > 1.6 * min(v) and k[0].endswith(", 16>"):      # two bench workloads on one (kernel, grid): split by duration
+            if max(v) > 1.6 * min(v) and ", 16, false>" in k[0]:      # two bench workloads on one (kernel, grid): split by duration
                 cut = (max(v) + min(v)) / 2
                 groups = [[x for x in v if x < cut], [x for x in v if x >= cut]]
             for g in groups:
@@ -82,7 +82,7 @@ for name, (prefix, K) in WL.items():
     for key in fetch:
         if key[0].startswith(prefix) and geom.get(name) in (key[1], key[1] // 8 if key[1] % 8 == 0 else -1):   # xcd_pack launches an 8x grid
             fv, wv = fetch[key], write.get(key, [])
-            if key[0].endswith(", 16>") and ("iiwa_14_7_k16384_f32" in geom and "iiwa_14_7_k131072_f32" in geom):
+            if ", 16, false>" in key[0] and ("iiwa_14_7_k16384_f32" in geom and "iiwa_14_7_k131072_f32" in geom):
                 big = name == "iiwa_14_7_k131072_f32"
                 fv = [v for v in fv if (v >= max(fetch[key]) / 2) == big]
                 wv = [v for v in wv if (v >= max(write[key]) / 2) == big] if wv else wv
