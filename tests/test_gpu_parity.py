@@ -657,3 +657,29 @@ def _read_iters(sol):
     rc = ct.CDLL("libamdhip64.so").hipMemcpy(buf, ct.c_void_p(sol.buffer_ptr(8)), 4, 2)
     assert rc == 0
     return bytes(buf)
+
+
+@pytest.mark.parametrize("S,C,K,dt,tol,mi,opts", [
+    (14, 7, 50, np.float64, 1e-9, 0, {}), (14, 7, 50, np.float64, 1e-9, 1, {}), (14, 7, 50, np.float64, 1e30, 50, {}),
+    (14, 7, 300, np.float64, 1e30, 50, {}), (14, 7, 300, np.float64, 1e-9, 0, {}),
+    (14, 7, 300, np.float64, 1e-9, 0, dict(pcg_mode=_lib.PCG_STREAMING)), (14, 7, 300, np.float64, 1e30, 5, dict(pcg_mode=_lib.PCG_STREAMING)),
+    (2, 1, 2, np.float64, 1e-12, 20, dict(pcg_groups=2)), (2, 1, 3, np.float64, 1e-12, 20, dict(pcg_groups=3)),
+    (2, 1, 1, np.float64, 1e-12, 20, {}), (14, 7, 2, np.float32, 1e-6, 20, dict(pcg_groups=2)),
+    (14, 7, 300, np.float64, 1e-9, 0, dict(pcg_variant=1)), (14, 7, 300, np.float64, 1e30, 5, dict(pcg_variant=1)),
+    (14, 7, 20000, np.float32, 1e30, 5, {}), (14, 7, 20000, np.float32, 1e-4, 0, {}), (14, 7, 20000, np.float32, 1e-4, 0, dict(pcg_semi=2))])
+def test_pcg_degenerate_iteration_counts_and_geometries(S, C, K, dt, tol, mi, opts):
+    """max_iters = 0 and 1, an exit test that is true at once (returned iters = 0 after ONE step, gato_pcg.cuh:404-411), one
+    knot per workgroup, one-knot systems - in every kernel family, against the oracle."""
+    s = synth.make_system(S, C, K, seed=1) if K > 1 else synth.blocks_to_csr(*synth.make_blocks(S, C, 1, 1, False))
+    Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
+    Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+    Pb = co.form_ss(Sb, Pb, S, K)
+    lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, tol, mi)
+    sol = make_solver(S, C, K, dt)
+    for k, v in opts.items():
+        sol.set_option(k, v)
+    lam, it = sol.pcg(sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam), tol, mi)
+    assert int(host(it)[0]) == it_o
+    scale = max(float(np.abs(lam_o).max()), 1e-30)
+    assert float(np.abs(host(lam).astype(np.float64) - lam_o).max()) / scale < (1e-10 if dt == np.float64 else 2e-3)
+    sol.close()
