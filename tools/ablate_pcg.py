@@ -1,3 +1,4 @@
+"""Timing-only ablations of the resident PCG iteration (option `ablate`, STAMP builds): which phase costs what."""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

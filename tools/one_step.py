@@ -1,3 +1,4 @@
+"""One whole solve step a few times (for rocprofv3 --kernel-trace + tools/trace_gaps.py): S C K B dtype [asm_mode]."""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

@@ -1,3 +1,4 @@
+"""cProfile of the Python side of gpu_library.linsys_solve at 14/7/50."""
 import os, sys, time, cProfile, pstats
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

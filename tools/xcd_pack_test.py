@@ -1,3 +1,4 @@
+"""us per iteration of 2..64-workgroup launches with the working groups packed on 1..7 XCDs (option xcd_pack)."""
 import sys, os, numpy as np
 sys.path.insert(0, os.getcwd())
 import torch
