@@ -683,3 +683,37 @@ def test_pcg_degenerate_iteration_counts_and_geometries(S, C, K, dt, tol, mi, op
     scale = max(float(np.abs(lam_o).max()), 1e-30)
     assert float(np.abs(host(lam).astype(np.float64) - lam_o).max()) / scale < (1e-10 if dt == np.float64 else 2e-3)
     sol.close()
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_csr_with_unsorted_columns_and_explicit_zeros(dt):
+    """The scatter takes CSR rows in any column order and with structurally present zeros (what a caller that builds CSR
+    by hand may pass; scipy's csr_matrix(dense) gives sorted, zero-free rows): both the per-knot gather kernel and the
+    fused assembly launch must give the oracle's dense blocks bit for bit."""
+    S, C, K = 14, 7, 12
+    s = synth.make_system(S, C, K, seed=31, dense_q=True)
+    rng = np.random.default_rng(5)
+
+    def shuffle(indptr, indices, data):
+        idx, dat, ptr = [], [], [0]
+        for r in range(len(indptr) - 1):
+            cols = list(indices[indptr[r]:indptr[r + 1]]); vals = list(data[indptr[r]:indptr[r + 1]])
+            perm = rng.permutation(len(cols))
+            idx += [cols[i] for i in perm]; dat += [vals[i] for i in perm]
+            ptr.append(len(idx))
+        return np.asarray(ptr, np.int32), np.asarray(idx, np.int32), np.asarray(dat, np.float64)
+
+    G_row, G_col, G_val = shuffle(s.G_row, s.G_col, s.G_val)
+    C_row, C_col, C_val = shuffle(s.C_row, s.C_col, s.C_val)
+    G_val[rng.random(len(G_val)) < 0.1] = 0.0                  # explicit zeros off the diagonal are just values
+    s2 = synth.KKTSystem(S, C, K, G_row, G_col, G_val, C_row, C_col, C_val, s.g, s.c, s.rho)
+    Gd_o, Cd_o = co.convert(*s2.csr_args()[:6], S, C, K, s2.rho, dt)
+    sol = make_solver(S, C, K, dt)
+    dev = sol.upload_system(s2)
+    Gd, Cd = sol.convert(*dev[:6], s2.rho)
+    assert np.array_equal(host(Gd), Gd_o) and np.array_equal(host(Cd), Cd_o)
+    for mode in (1, 2):
+        sol.set_option("asm_mode", mode)
+        sol.linsys(*dev, 1e-8, 5, s2.rho)
+        assert np.array_equal(sol.read_buffer("G_dense"), Gd_o) and np.array_equal(sol.read_buffer("C_dense"), Cd_o)
+    sol.close()
