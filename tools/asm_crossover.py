@@ -26,7 +26,8 @@ def run(S, C, K, dt, B, mode, iters=10, reps=30):
     sol.close()
     return best * 1e6
 
-for (S, C, K, dt, B) in [(14, 7, 50, np.float64, 1), (14, 7, 50, np.float32, 1), (14, 7, 512, np.float32, 1), (14, 7, 2048, np.float32, 1),
+if __name__ == "__main__":
+  for (S, C, K, dt, B) in [(14, 7, 50, np.float64, 1), (14, 7, 50, np.float32, 1), (14, 7, 512, np.float32, 1), (14, 7, 2048, np.float32, 1),
                          (14, 7, 4096, np.float32, 1), (14, 7, 4096, np.float64, 1), (32, 16, 50, np.float64, 1), (32, 16, 1024, np.float32, 1),
                          (14, 7, 50, np.float64, 8), (14, 7, 50, np.float64, 64), (14, 7, 50, np.float64, 512), (14, 7, 50, np.float32, 512),
                          (2, 1, 5, np.float32, 1), (14, 7, 16384, np.float32, 1)]:
