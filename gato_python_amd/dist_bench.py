@@ -209,9 +209,13 @@ def main(args):
         out = sharded_leg(args, torch, dist, rank, local, world, wl, args.steps, args.warmup)
     else:
         out = replicas_leg(args, torch, dist, rank, local, world)
-        sh = sharded_leg(args, torch, dist, rank, local, world, "sharded_k4096_f32", min(args.steps, 20), min(args.warmup, 3))
-        if rank == 0:
-            out["sharded"] = {k: sh[k] for k in ("value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline", "parity")}
+        try:            # the line above must survive whatever happens in the rider (an error raised on every rank alike)
+            sh = sharded_leg(args, torch, dist, rank, local, world, "sharded_k4096_f32", min(args.steps, 20), min(args.warmup, 3))
+            if rank == 0:
+                out["sharded"] = {k: sh[k] for k in ("value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline", "parity")}
+        except Exception as e:   # noqa: BLE001
+            if rank == 0:
+                out["sharded"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         print(json.dumps(out))
     dist.destroy_process_group()
