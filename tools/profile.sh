@@ -13,4 +13,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_write -- python3 $R/bench.py $ARGS > /dev/null 2> $R/gpurun_out/prof_${TAG}_write.err || exit 1
 # matrix-core evidence for the assembly stages (the only dense contractions of the path)
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_mfma -- python3 $R/bench.py $ARGS > /dev/null 2> $R/gpurun_out/prof_${TAG}_mfma.err || exit 1
+# what bounds the register-resident loop of the default workload: VALU / LDS activity and waits (two passes, default workload only)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_issue1 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-sweep > /dev/null 2> $R/gpurun_out/prof_${TAG}_issue1.err || exit 1
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_issue2 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-sweep > /dev/null 2> $R/gpurun_out/prof_${TAG}_issue2.err || exit 1
 echo profile $TAG done

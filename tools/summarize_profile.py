@@ -135,4 +135,19 @@ if mf:
         for k, v in sorted(acc.items()):
             row = [f"{sum(v[n]) / len(v[n]):.0f}" if v.get(n) else "" for n in names]
             f.write(f'"{k[0]}",{k[1]},{len(next(iter(v.values())))},' + ",".join(row) + "\n")
+# issue / LDS activity of the PCG kernels of the default workload
+rows = defaultdict(lambda: defaultdict(list))
+for kind in ("issue1", "issue2"):
+    p = one(f"prof_{tag}_{kind}/*/*_counter_collection.csv")
+    if p:
+        for r in csv.DictReader(open(p)):
+            if "pcg_" in r["Kernel_Name"]:
+                rows[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if rows:
+    names = ["SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE",
+             "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU"]
+    with open(os.path.join(out, f"{tag}_pcg_issue.csv"), "w") as f:
+        f.write("kernel,grid_threads,launches," + ",".join(n + "_avg" for n in names) + "\n")
+        for k, v in sorted(rows.items()):
+            f.write(f'"{k[0]}",{k[1]},{len(next(iter(v.values())))},' + ",".join(f"{sum(v[n]) / len(v[n]):.0f}" if v.get(n) else "" for n in names) + "\n")
 print("wrote", sorted(os.listdir(out)))
