@@ -1,0 +1,93 @@
+// Micro-benchmark: round-trip time of an 8-byte {epoch,payload} hand-off between two workgroups, by cache-control
+// variant of the store / poll, for workgroups on the SAME XCD (blocks 0 and 8) and on different XCDs (blocks 0 and 1).
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/pingpong.hip -o /tmp/pingpong && /tmp/pingpong
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef unsigned long long u64;
+
+// V = 10 * store variant + load variant
+template <int V> __device__ __forceinline__ void st(u64 *p, u64 v)
+{
+    constexpr int SV = V / 10;
+    if (SV == 0) asm volatile("global_store_dwordx2 %0, %1, off sc1\n" ::"v"(p), "v"(v) : "memory");            // agent scope (today)
+    else if (SV == 1) asm volatile("global_store_dwordx2 %0, %1, off sc0\n" ::"v"(p), "v"(v) : "memory");
+    else if (SV == 2) asm volatile("global_store_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" ::"v"(p), "v"(v) : "memory");
+    else if (SV == 3) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)\n\tbuffer_wbl2 sc0\n\ts_waitcnt vmcnt(0)" ::"v"(p), "v"(v) : "memory");
+}
+template <int V> __device__ __forceinline__ u64 ld(u64 *p)
+{
+    constexpr int LV = V % 10;
+    u64 v;
+    if (LV == 0) asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else if (LV == 1) asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else if (LV == 2) asm volatile("buffer_inv sc0\n\tglobal_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else if (LV == 3) asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else if (LV == 4) asm volatile("global_load_dwordx2 %0, %1, off sc0 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else asm volatile("buffer_inv sc1\n\tglobal_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <int V>
+__global__ void pingpong(u64 *slots, int partner_block, int rounds, u64 *out, int *xcc)
+{
+    const int me = blockIdx.x == 0 ? 0 : (blockIdx.x == partner_block ? 1 : -1);
+    if (me < 0 || threadIdx.x != 0) return;
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    xcc[me] = (int)(id & 0xf);
+    u64 *mine = slots + me * 32, *theirs = slots + (1 - me) * 32;      // 256 B apart: separate lines
+    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    int ok = 1;
+    for (int r = 1; r <= rounds && ok; ++r) {
+        if (me == 0) st<V>(mine, ((u64)r << 32) | 1u);
+        u64 v = 0;
+        for (unsigned spin = 0;; ++spin) {
+            v = ld<V>(theirs);
+            if ((unsigned)(v >> 32) == (unsigned)r) break;
+            if ((spin & 1023u) == 1023u && __builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) { ok = 0; break; }   // 0.2 s
+        }
+        if (me == 1) st<V>(mine, ((u64)r << 32) | 2u);
+    }
+    out[me * 2] = __builtin_amdgcn_s_memrealtime() - t0;
+    out[me * 2 + 1] = (u64)ok;
+}
+
+template <int V> void run(const char *name, int partner)
+{
+    u64 *slots, *out; int *xcc;
+    hipMalloc(&slots, 4096); hipMemset(slots, 0, 4096);
+    hipMalloc(&out, 64); hipMemset(out, 0, 64);
+    hipMalloc(&xcc, 16);
+    const int rounds = 5000;
+    hipLaunchKernelGGL(pingpong<V>, dim3(partner + 1), dim3(64), 0, 0, slots, partner, rounds, out, xcc);
+    hipDeviceSynchronize();
+    u64 h[4]; int hx[2];
+    hipMemcpy(h, out, 32, hipMemcpyDeviceToHost); hipMemcpy(hx, xcc, 8, hipMemcpyDeviceToHost);
+    printf("%-34s partner block %d (XCC %d / %d): %s, %.0f ns per round trip (= 2 one-way hand-offs)\n", name, partner, hx[0], hx[1],
+           h[1] && h[3] ? "completed" : "TIMED OUT (stale reads)", h[0] * 10.0 / rounds);
+    hipFree(slots); hipFree(out); hipFree(xcc);
+}
+
+template <int V> void both(const char *name) { run<V>(name, 8); run<V>(name, 1); }
+
+int main()
+{
+    both<0>("st sc1 / ld sc1 (agent, today)");
+    both<1>("st sc1 / ld sc0");
+    both<2>("st sc1 / inv sc0 + ld");
+    both<3>("st sc1 / ld nt");
+    both<4>("st sc1 / ld sc0 nt");
+    both<10>("st sc0 / ld sc1");
+    both<20>("st plain+wait / ld sc1");
+    both<40>("st plain+wbl2 sc0 / ld sc1");
+    both<11>("st sc0 / ld sc0");
+    both<12>("st sc0 / inv sc0 + ld");
+    both<22>("st plain+wait / inv sc0 + ld");
+    both<42>("st plain+wbl2 / inv sc0 + ld");
+    both<30>("st sc0 sc1 / ld sc1");
+    both<5>("st sc1 / inv sc1 + ld");
+    return 0;
+}
