@@ -71,10 +71,61 @@ template <int V> void run(const char *name, int partner)
     hipFree(slots); hipFree(out); hipFree(xcc);
 }
 
+// All-to-all: W workgroups (one polling wave each, optionally a workgroup barrier per round as in the PCG kernel), every
+// round each publishes one granule and waits for all W - the floor of the PCG hand-off, without any arithmetic.
+__global__ void allgather(u64 *slots, int W, int pack, int rounds, int with_barrier, u64 *out)
+{
+    if (pack && (blockIdx.x & 7) != 0) return;
+    const int wg = pack ? blockIdx.x >> 3 : blockIdx.x;
+    if (wg >= W) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    int ok = 1;
+    for (int r = 1; r <= rounds; ++r) {
+        u64 *base = slots + (size_t)(r & 1) * W * 32;
+        if (wave == 0) {
+            if (lane == 0) st<0>(base + wg * 32, ((u64)r << 32) | (unsigned)wg);
+            u64 *p = base + (size_t)(lane < W ? lane : W - 1) * 32;
+            for (unsigned spin = 0;; ++spin) {
+                const u64 v = ld<0>(p);
+                if (__all((unsigned)(v >> 32) == (unsigned)r)) break;
+                if ((spin & 1023u) == 1023u && __builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) { ok = 0; break; }
+            }
+        }
+        if (with_barrier) __syncthreads();
+        if (!ok) break;
+    }
+    if (wg == 0 && threadIdx.x == 0) { out[0] = __builtin_amdgcn_s_memrealtime() - t0; out[1] = (u64)ok; }
+}
+
+void run_allgather(int W, int pack, int threads, int with_barrier)
+{
+    u64 *slots, *out;
+    hipMalloc(&slots, 2 * 64 * 256 + 4096); hipMemset(slots, 0, 2 * 64 * 256 + 4096);
+    hipMalloc(&out, 64); hipMemset(out, 0, 64);
+    const int rounds = 20000;
+    hipLaunchKernelGGL(allgather, dim3(pack ? 8 * W : W), dim3(threads), 0, 0, slots, W, pack, rounds, with_barrier, out);
+    hipDeviceSynchronize();
+    u64 h[2];
+    hipMemcpy(h, out, 16, hipMemcpyDeviceToHost);
+    printf("all-to-all W=%2d %-8s %3d threads %-12s: %s, %.0f ns per round\n", W, pack ? "one XCD" : "spread", threads,
+           with_barrier ? "with barrier" : "no barrier", h[1] ? "completed" : "TIMED OUT", h[0] * 10.0 / rounds);
+    hipFree(slots); hipFree(out);
+}
+
 template <int V> void both(const char *name) { run<V>(name, 8); run<V>(name, 1); }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1) {
+        for (int W : {2, 4, 15, 29, 32})
+            for (int pack : {1, 0}) {
+                run_allgather(W, pack, 64, 0);
+                run_allgather(W, pack, 512, 1);
+            }
+        for (int W : {57, 64}) { run_allgather(W, 0, 64, 0); run_allgather(W, 0, 512, 1); }
+        return 0;
+    }
     both<0>("st sc1 / ld sc1 (agent, today)");
     both<1>("st sc1 / ld sc0");
     both<2>("st sc1 / inv sc0 + ld");
