@@ -165,7 +165,7 @@ def cpu_baseline(sysm, dt, budget_s=10.0):
     """The C restatement (oracle/, test infrastructure) timed on the host as the reported CPU baseline."""
     from oracle import c_oracle as co
     S, C, K = sysm.S, sysm.C, sysm.K
-    best = None
+    best, tried = None, []
     # thread counts tried: 1 and the box's CPU share (the GPU boxes expose all host cores but grant ~16 per GPU;
     # oversubscribing the OpenMP loops beyond that only slows them down)
     try:
@@ -183,10 +183,12 @@ def cpu_baseline(sysm, dt, budget_s=10.0):
             if el > budget_s / 2 or n >= 20000:
                 break
         v = MAX_ITERS * n / el
+        tried.append({"cores": threads, "value": v})
         if best is None or v > best["value"]:
             best = dict(value=v, unit="PCG iterations/s", cores=threads, kind="port",
                         sample=f"{n} whole solves (assembly + {MAX_ITERS} PCG iterations + dz) of the same "
                                f"{S}/{C}/{K} {dtype_name(dt)} system in {el:.1f} s, oracle/gato_oracle_impl.h")
+    best["tried"] = tried                 # every thread count timed (1 and the box's CPU share); value = the best of them
     return best
 
 
