@@ -27,7 +27,9 @@ SYMBOLS = [
     "gato_form_ss", "gato_pcg", "gato_pcg_status", "gato_pcg_last_ms", "gato_compute_dz", "gato_linsys_device",
     "gato_linsys_solve_f32", "gato_linsys_solve_f64",
     "gato_shard_pcg_init", "gato_shard_pcg_phase_a", "gato_shard_pcg_phase_b", "gato_shard_pcg_finish",
-    "gato_shard_pcg_done", "gato_linsys_device_blocks", "gato_release_cache",
+    "gato_shard_pcg_done", "gato_linsys_device_blocks", "gato_release_cache", "gato_solver_recover",
+    "gato_cluster_knot_range", "gato_cluster_create", "gato_cluster_local_mirror", "gato_cluster_connect",
+    "gato_cluster_pcg", "gato_cluster_destroy",
 ]
 
 
@@ -84,6 +86,14 @@ def lib() -> ct.CDLL:
         L.gato_shard_pcg_finish.argtypes = [vp, vp, vp, vp, vp]
         L.gato_shard_pcg_done.argtypes = [vp, ct.POINTER(ct.c_int), vp]
         L.gato_linsys_device_blocks.argtypes = [vp, vp, vp, vp, vp, d, i, d, vp, vp, vp]
+        L.gato_solver_recover.argtypes = [vp, ct.POINTER(ct.c_int), vp]
+        L.gato_cluster_knot_range.argtypes = [i, i, i, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int)]
+        L.gato_cluster_create.argtypes = [vp, i, i, vp]
+        L.gato_cluster_local_mirror.argtypes = [vp]
+        L.gato_cluster_local_mirror.restype = ct.c_void_p
+        L.gato_cluster_connect.argtypes = [vp, vp, vp]
+        L.gato_cluster_pcg.argtypes = [vp, vp, vp, vp, vp, d, i, vp, vp]
+        L.gato_cluster_destroy.argtypes = [vp]
         f = ct.c_float
         L.gato_linsys_solve_f32.argtypes = [ip, i, ip, vp, i, ip, i, ip, vp, i, vp, i, vp, i, vp,
                                             i, i, i, i, f, i, i, f, vp, vp, vp, vp]

@@ -135,7 +135,76 @@ struct gato_solver {
     int last_asm_fused, stamp_asm;
     double *eta_hist;   // eta after init and after every iteration (option record_eta), GATO_ETA_HIST_MAX + 1 entries
     int record_eta;
+    // hand-off time-outs: the status word holds the id of the most recent launch that timed out (never cleared by a
+    // kernel); ids only grow, so "status differs from the last acknowledged value" = a time-out since the last check
+    int status_ack;
+    hipStream_t last_stream;          // stream of the most recent PCG launch (gato_pcg_status synchronises it)
+    int timeout_ms;                   // option: bound of every in-kernel spin (default 2000)
+    int max_workgroups;               // option: CUs a persistent launch may count on (0 = all; ranks sharing one GPU in tests)
+    int last_fallback;                // the most recent gato_solver_recover re-ran the PCG through the streaming kernels
+    struct {                          // arguments of the most recent whole solve, for gato_solver_recover
+        int valid;
+        const void *S, *P, *gamma, *Cd, *g;
+        void *lam, *dz;
+        double exit_tol;
+        int max_iters;
+    } lc;
+    // multi-GPU cluster (gato_cluster_*): this rank's mirror, the peers' mirrors as mapped here
+    struct {
+        int on, rank, nranks, k0, k1;
+        unsigned long long *local;
+        unsigned long long *peer[GATO_MAX_RANKS];
+        bool opened[GATO_MAX_RANKS];
+        size_t bytes;
+        unsigned xepoch;
+        int mem_kind;                 // 0 uncached, 1 fine-grained, 2 plain hipMalloc
+    } cl;
+    unsigned long long **cl_tab;      // device copy of cl.peer (the kernel reads the peers' mirror addresses from it)
 };
+
+// ---- co-residency gate (A12: check_sms + cudaLaunchCooperativeKernel in the reference, gato_utils.cuh:829-854,
+// gato_pcg.cuh:502-526).  The workgroups of a multi-workgroup persistent launch hand data to each other inside the
+// launch, so all of them must be resident at once.  One launch alone always is (W <= CUs, one workgroup per CU); two
+// launches on two streams of one process could each get half their workgroups and spin until the time-out.  Every
+// such launch therefore records an event, and a launch that would not fit beside the launches still in flight on OTHER
+// streams of the same device first makes its stream wait for them.  (Kernels of foreign processes cannot be seen here:
+// that case ends in the bounded time-out and gato_solver_recover.)
+namespace {
+struct InFlight { hipEvent_t ev; int cus; hipStream_t st; int device; };
+std::mutex g_gate_mu;
+std::vector<InFlight> g_inflight;
+std::vector<hipEvent_t> g_free_events;
+
+int gate_before(int device, int num_cus, int need, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(g_gate_mu);
+    size_t w = 0;
+    for (size_t i = 0; i < g_inflight.size(); ++i) {
+        if (hipEventQuery(g_inflight[i].ev) == hipSuccess) g_free_events.push_back(g_inflight[i].ev);
+        else g_inflight[w++] = g_inflight[i];
+    }
+    g_inflight.resize(w);
+    int busy = 0;
+    for (const InFlight &f : g_inflight)
+        if (f.device == device && f.st != st) busy += f.cus;
+    if (busy + need > num_cus) {
+        for (const InFlight &f : g_inflight)
+            if (f.device == device && f.st != st) GATO_HIP_CHECK(hipStreamWaitEvent(st, f.ev, 0));
+    }
+    return GATO_OK;
+}
+
+int gate_after(int device, int need, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(g_gate_mu);
+    hipEvent_t ev = nullptr;
+    if (!g_free_events.empty()) { ev = g_free_events.back(); g_free_events.pop_back(); }
+    else GATO_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    GATO_HIP_CHECK(hipEventRecord(ev, st));
+    g_inflight.push_back(InFlight{ev, need, st, device});
+    return GATO_OK;
+}
+}  // namespace
 
 static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -219,6 +288,11 @@ extern "C" int gato_infer_shape(const int *C_row, int len_C_row, int len_g, int 
 }
 
 extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype, int device, gato_solver **out);
+extern "C" int gato_cluster_destroy(gato_solver *s);
+extern "C" int gato_compute_dz(gato_solver *s, const void *d_Ginv_dense, const void *d_C_dense, const void *d_g,
+                               const void *d_lambda, void *d_dz, void *stream);
+extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
+                        double exit_tol, int max_iters, int *d_iters, void *stream);
 
 extern "C" int gato_solver_create(int S, int C, int K, int dtype, int device, gato_solver **out)
 {
@@ -258,6 +332,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     s->pcg_mode = GATO_PCG_AUTO;
     s->xcd_pack = -1;
     s->pcg_semi = -1;
+    s->timeout_ms = 2000;
 
     const Dims &d = s->d;
     const size_t e = s->esz;
@@ -279,6 +354,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     const size_t o_part = take((size_t)4 * max_groups * e), o_scal = take(64 * 8), o_done = take(64);
     const size_t o_gh = take((size_t)8 * S * e);
     const size_t o_hist = take(sizeof(double) * (GATO_ETA_HIST_MAX + 1));
+    const size_t o_xtab = take(sizeof(void *) * GATO_MAX_RANKS);
     s->arena_bytes = off;
     GATO_HIP_CHECK(hipMalloc((void **)&s->arena, off));
     GATO_HIP_CHECK(hipMemset(s->arena, 0, off));
@@ -294,6 +370,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     s->sw.max_groups = max_groups;
     s->ghosts = a + o_gh;
     s->eta_hist = (double *)(a + o_hist);
+    s->cl_tab = (unsigned long long **)(a + o_xtab);
     *out = s;
     return GATO_OK;
 }
@@ -301,12 +378,13 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
 extern "C" int gato_solver_destroy(gato_solver *s)
 {
     if (!s) return GATO_OK;
-    hipSetDevice(s->device);
-    if (s->ev_pcg0) hipEventDestroy(s->ev_pcg0);
-    if (s->ev_pcg1) hipEventDestroy(s->ev_pcg1);
-    if (s->arena) hipFree(s->arena);
-    if (s->in_arena) hipFree(s->in_arena);
-    if (s->pin) hipHostFree(s->pin);
+    (void)hipSetDevice(s->device);
+    gato_cluster_destroy(s);
+    if (s->ev_pcg0) (void)hipEventDestroy(s->ev_pcg0);
+    if (s->ev_pcg1) (void)hipEventDestroy(s->ev_pcg1);
+    if (s->arena) (void)hipFree(s->arena);
+    if (s->in_arena) (void)hipFree(s->in_arena);
+    if (s->pin) (void)hipHostFree(s->pin);
     delete s;
     return GATO_OK;
 }
@@ -338,7 +416,6 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "pcg_semi")) s->pcg_semi = value;
     else if (!strcmp(name, "pcg_epoch")) s->pcg_epoch = (unsigned)value;      // test hook: place the counter near its wrap
     else if (!strcmp(name, "stamp_asm")) s->stamp_asm = value;
-    else if (!strcmp(name, "stamp_asm")) s->stamp_asm = value;
     else if (!strcmp(name, "stamp_pcg")) s->stamp_pcg = value;
     else if (!strcmp(name, "ablate")) s->ablate = value;
     else if (!strcmp(name, "no_single_lds")) s->no_single_lds = value;
@@ -347,6 +424,8 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "record_eta")) s->record_eta = value;
     else if (!strcmp(name, "xcd_pack")) s->xcd_pack = value;
     else if (!strcmp(name, "true_warm_start")) s->true_warm_start = value;
+    else if (!strcmp(name, "timeout_ms")) s->timeout_ms = value > 0 ? value : 2000;
+    else if (!strcmp(name, "max_workgroups")) s->max_workgroups = value;
     else if (!strcmp(name, "batch_nnz_G")) s->d.nnzG = value;
     else if (!strcmp(name, "batch_nnz_C")) s->d.nnzC = value;
     else if (!strcmp(name, "time_pcg")) {
@@ -381,6 +460,9 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "asm_mode")) *value = s->asm_mode;
     else if (!strcmp(name, "last_asm_fused")) *value = s->last_asm_fused;
     else if (!strcmp(name, "last_semi")) *value = s->last_semi;
+    else if (!strcmp(name, "last_fallback")) *value = s->last_fallback;
+    else if (!strcmp(name, "timeout_ms")) *value = s->timeout_ms;
+    else if (!strcmp(name, "cluster_mem_kind")) *value = s->cl.on ? s->cl.mem_kind : -1;
     else if (!strcmp(name, "num_cus")) *value = s->num_cus;
     else if (!strcmp(name, "batch")) *value = s->d.B;
     else if (!strcmp(name, "max_semi_knots"))
@@ -419,10 +501,18 @@ extern "C" int gato_form_ss(gato_solver *s, const void *d_S, void *d_Pinv, void 
 
 // Geometry of the resident launch.  One workgroup per CU at most (all workgroups must be
 // co-resident: they hand partial dots and halo blocks to each other inside the launch).
+static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int *kpw);
 static int plan_resident(gato_solver *s, int *groups, int *threads, int *kpw)
 {
-    const int S = s->d.S, K = s->d.K;
-    const int max_wg = s->num_cus < 256 ? s->num_cus : 256;
+    return plan_resident_k(s, s->d.K, groups, threads, kpw);
+}
+
+// K = knots the launch works on (the system's, or one rank's shard of it)
+static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int *kpw)
+{
+    const int S = s->d.S;
+    int max_wg = s->num_cus < 256 ? s->num_cus : 256;
+    if (s->max_workgroups > 0 && s->max_workgroups < max_wg) max_wg = s->max_workgroups;   // CUs this solver may count on
     int t = s->pcg_threads;
     int g = s->pcg_groups;
     const int maxT = s->plan.max_threads;
@@ -558,6 +648,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
             else a.xcd_pack = (s->xcd_pack >= need && s->xcd_pack < 8) ? s->xcd_pack : 0;
         }
         if (a.semi) a.xcd_pack = 0;
+        if (a.xcd_pack > 0 && groups > s->num_cus / 8) a.xcd_pack = 0;     // an XCD with fewer CUs than workgroups (CU mask): plain grid
         a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
         a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
         // hand-off epochs: each launch gets a fresh range (two reductions per iteration plus the initial one)
@@ -572,7 +663,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.launch_id = s->pcg_launch_id;
         a.final_eta = s->final_eta;
         a.eta_hist = (s->record_eta && max_iters <= GATO_ETA_HIST_MAX) ? s->eta_hist : nullptr;
-        a.timeout_ticks = 200000000ull;   // 2 s at 100 MHz
+        a.timeout_ticks = (unsigned long long)s->timeout_ms * 100000ull;   // s_memrealtime runs at 100 MHz
         a.ablate = s->ablate;
         a.stamps = s->stamp_pcg ? (unsigned long long *)s->sw.scalars + 8 : nullptr;
         a.ev_start = s->time_pcg ? s->ev_pcg0 : nullptr;
@@ -580,8 +671,18 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT;
         s->last_variant = cg1 ? 1 : 0;
         s->last_semi = a.semi;
-        return cg1 ? s->ops->pcg_cg1(a, st) : s->ops->pcg_resident(a, st);
+        s->last_stream = st;
+        // co-residency: a multi-workgroup launch waits for launches on other streams it would not fit beside
+        // (a one-XCD launch counts as the whole chip: two of them may be dealt to the same XCD)
+        const bool gated = batch == 1 && groups > 1;
+        const int need_cus = a.xcd_pack > 0 ? s->num_cus : groups;
+        int rc;
+        if (gated && (rc = gate_before(s->device, s->num_cus, need_cus, st))) return rc;
+        rc = cg1 ? s->ops->pcg_cg1(a, st) : s->ops->pcg_resident(a, st);
+        if (rc == GATO_OK && gated) rc = gate_after(s->device, need_cus, st);
+        return rc;
     }
+    s->last_stream = st;
     s->last_mode = GATO_PCG_STREAMING; s->last_groups = 0; s->last_threads = 0; s->last_semi = 0;
     s->sw.warm_start = s->true_warm_start;
     s->sw.eta_hist = (s->record_eta && max_iters <= GATO_ETA_HIST_MAX) ? s->eta_hist : nullptr;
@@ -614,12 +715,43 @@ extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, con
     return GATO_OK;
 }
 
+// Reports a hand-off time-out of ANY PCG launch since the previous call (the status word keeps the id of the most
+// recent launch that timed out; no kernel ever clears it), after synchronising the stream of the latest launch.
+// The same condition is visible in-band: the launch wrote iters = -1.
 extern "C" int gato_pcg_status(gato_solver *s, int *status)
 {
     int v = 0;
+    GATO_HIP_CHECK(hipSetDevice(s->device));
+    GATO_HIP_CHECK(hipStreamSynchronize(s->last_stream));
     GATO_HIP_CHECK(hipMemcpy(&v, s->status, sizeof(int), hipMemcpyDeviceToHost));
-    if (status) *status = v;
-    if (v != 0 && v == s->pcg_launch_id) { set_error("pcg: in-kernel hand-off timed out"); return GATO_ETIMEOUT; }
+    const bool timed_out = v != s->status_ack;
+    s->status_ack = v;
+    if (status) *status = timed_out ? 1 : 0;
+    if (timed_out) { set_error("pcg: in-kernel hand-off timed out (launch %d)", v); return GATO_ETIMEOUT; }
+    return GATO_OK;
+}
+
+// A12 fallback: if a persistent launch of the most recent whole solve (gato_linsys_device / _blocks) gave up on a
+// hand-off - its workgroups were not co-resident, e.g. another process held the CUs - the PCG is re-run through the
+// streaming kernels (no inter-workgroup hand-off inside a launch, any residency) and dz is recomputed: a slower
+// correct answer instead of an error.  Synchronises `stream`.  *recovered = 1 when that happened.
+extern "C" int gato_solver_recover(gato_solver *s, int *recovered, void *stream)
+{
+    if (recovered) *recovered = 0;
+    s->last_fallback = 0;
+    int st_ = 0;
+    const int rc = gato_pcg_status(s, &st_);
+    if (rc == GATO_OK) return GATO_OK;
+    if (rc != GATO_ETIMEOUT || !s->lc.valid) return rc;
+    const int saved = s->pcg_mode;
+    s->pcg_mode = GATO_PCG_STREAMING;
+    int rc2 = gato_pcg(s, s->lc.S, s->lc.P, s->lc.gamma, s->lc.lam, s->lc.exit_tol, s->lc.max_iters, s->iters, stream);
+    s->pcg_mode = saved;
+    if (rc2) return rc2;
+    if (s->lc.dz && (rc2 = gato_compute_dz(s, s->Ginv, s->lc.Cd, s->lc.g, s->lc.lam, s->lc.dz, stream))) return rc2;
+    GATO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    s->last_fallback = 1;
+    if (recovered) *recovered = 1;
     return GATO_OK;
 }
 
@@ -671,6 +803,7 @@ extern "C" int gato_linsys_device(gato_solver *s, const int *d_G_row, const int 
     void *lam = d_lambda ? d_lambda : s->lambda;
     void *dz = d_dz ? d_dz : s->dz;
     if ((rc = assemble(s, 0, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, s->C_dense, d_g, d_c, rho, (hipStream_t)stream))) return rc;
+    s->lc = {1, s->Sbd, s->Pbd, s->gamma, s->C_dense, d_g, lam, dz, exit_tol, max_iters};
     if ((rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream))) return rc;
     if ((rc = gato_compute_dz(s, s->Ginv, s->C_dense, d_g, lam, dz, stream))) return rc;
     return GATO_OK;
@@ -684,6 +817,7 @@ extern "C" int gato_linsys_device_blocks(gato_solver *s, const void *d_G_blocks,
     void *lam = d_lambda ? d_lambda : s->lambda;
     void *dz = d_dz ? d_dz : s->dz;
     if ((rc = assemble(s, 2, nullptr, nullptr, d_G_blocks, nullptr, nullptr, nullptr, d_C_blocks, d_g, d_c, rho, (hipStream_t)stream))) return rc;
+    s->lc = {1, s->Sbd, s->Pbd, s->gamma, d_C_blocks, d_g, lam, dz, exit_tol, max_iters};
     if ((rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream))) return rc;
     return gato_compute_dz(s, s->Ginv, d_C_blocks, d_g, lam, dz, stream);
 }
@@ -773,7 +907,7 @@ static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const i
         if ((rc = gato_solver_create(S, C, K, dtype, 0, &s))) return rc;
         cached = s;
     } else {
-        hipSetDevice(s->device);
+        (void)hipSetDevice(s->device);
     }
     const char *env = getenv("GATO_PCG_MODE");
     s->pcg_mode = env ? atoi(env) : GATO_PCG_AUTO;
@@ -785,7 +919,7 @@ static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const i
     const size_t og = take(sizeof(T) * len_g), oc = take(sizeof(T) * len_c);
     hipError_t e = hipSuccess;
     if (s->in_bytes < off) {
-        if (s->in_arena) hipFree(s->in_arena);
+        if (s->in_arena) (void)hipFree(s->in_arena);
         s->in_arena = nullptr; s->in_bytes = 0;
         e = hipMalloc((void **)&s->in_arena, off);
         if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", off, hipGetErrorString(e)); return GATO_EHIP; }
@@ -794,11 +928,11 @@ static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const i
     char *a = s->in_arena;
     hipStream_t st = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    auto fail = [&](int code) { if (ev0) hipEventDestroy(ev0); if (ev1) hipEventDestroy(ev1); return code; };
+    auto fail = [&](int code) { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); return code; };
     // one H2D transfer: the eight input arrays are packed into a pinned staging buffer laid out like the device
     // arena (the reference issues eight blocking cudaMemcpy from pageable memory, gpu_library.cu:150-157)
     if (s->pin_bytes < off + 64 + sizeof(T) * ((size_t)S * K + (size_t)N)) {
-        if (s->pin) hipHostFree(s->pin);
+        if (s->pin) (void)hipHostFree(s->pin);
         s->pin = nullptr; s->pin_bytes = 0;
         const size_t want = off + 64 + sizeof(T) * ((size_t)S * K + (size_t)N) + 256;
         if ((e = hipHostMalloc((void **)&s->pin, want, hipHostMallocDefault)) != hipSuccess) {
@@ -816,11 +950,11 @@ static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const i
         return fail(GATO_EHIP);
     }
     char *pout = s->pin + off;                               // pinned landing area: iters | lambda | dz
-    hipEventCreate(&ev0);
-    hipEventCreate(&ev1);
+    (void)hipEventCreate(&ev0);
+    (void)hipEventCreate(&ev1);
     int iters = 0;
     for (int i = 0; i < testiters; ++i) {                       // gpu_library.cu:169-192
-        hipEventRecord(ev0, st);
+        (void)hipEventRecord(ev0, st);
         rc = gato_linsys_device(s, (const int *)(a + oGr), (const int *)(a + oGc), a + oGv, (const int *)(a + oCr),
                                 (const int *)(a + oCc), a + oCv, a + og, a + oc, (double)exit_tol, max_iters,
                                 (double)rho, nullptr, nullptr, st);
@@ -831,17 +965,31 @@ static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const i
             set_error("D2H copy failed: %s", hipGetErrorString(e));
             return fail(GATO_EHIP);
         }
-        hipEventRecord(ev1, st);
+        (void)hipEventRecord(ev1, st);
         if ((e = hipEventSynchronize(ev1)) != hipSuccess) {
             set_error("solve failed: %s", hipGetErrorString(e));
             return fail(GATO_EHIP);
         }
         iters = *(const int *)pout;
+        if (iters < 0) {
+            // in-band time-out mark of a persistent launch (its workgroups were not co-resident): slower correct answer
+            // through the streaming kernels instead of an error, then fetch the results again
+            int recovered = 0;
+            if ((rc = gato_solver_recover(s, &recovered, st))) return fail(rc);
+            if ((e = hipMemcpy(pout + 64, s->lambda, sizeof(T) * (size_t)S * K, hipMemcpyDeviceToHost)) != hipSuccess ||
+                (e = hipMemcpy(pout + 64 + sizeof(T) * (size_t)S * K, s->dz, sizeof(T) * (size_t)N, hipMemcpyDeviceToHost)) != hipSuccess ||
+                (e = hipMemcpy(pout, s->iters, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) {
+                set_error("D2H copy failed: %s", hipGetErrorString(e));
+                return fail(GATO_EHIP);
+            }
+            (void)hipEventRecord(ev1, st);
+            (void)hipEventSynchronize(ev1);
+            iters = *(const int *)pout;
+        }
         float ms = 0;
-        hipEventElapsedTime(&ms, ev0, ev1);
+        (void)hipEventElapsedTime(&ms, ev0, ev1);
         if (ms_out) ms_out[i] = ms;
         if (i == 0 && iters_out) *iters_out = iters;            // the reference prints the first run's count (:189-191)
-        if ((rc = gato_pcg_status(s, nullptr))) return fail(rc);
     }
     memcpy(lambda_out, pout + 64, sizeof(T) * (size_t)S * K);
     memcpy(dz_out, pout + 64 + sizeof(T) * (size_t)S * K, sizeof(T) * (size_t)N);
@@ -990,4 +1138,164 @@ extern "C" int gato_shard_pcg_finish(gato_solver *s, const void *d_recvB_last, v
     if (d_iters && d_iters != s->iters)
         GATO_HIP_CHECK(hipMemcpyAsync(d_iters, s->iters, sizeof(int), hipMemcpyDeviceToDevice, st));
     return GATO_OK;
+}
+
+// ---- multi-GPU cluster: the persistent PCG launch with a device-initiated cross-GPU hand-off level --------------------
+// NEW work: the reference is single-device (gato_utils.cuh:831) and has no communication layer.
+// One process per GPU.  Every rank owns a MIRROR - a few KB of fine-grained device memory, IPC-shared - into which the
+// peers store {epoch, payload} granules with system-scope stores over xGMI; a rank only ever polls its own mirror.  See
+// pcg_resident_kernel<..., MR = true> for the protocol.  RCCL (gato_shard_pcg_*) stays as the portable fallback.
+static int cluster_alloc(gato_solver *s)
+{
+    const char *env = getenv("GATO_XMEM");           // uncached | finegrained | plain (default: first that works)
+    const int first = env ? (!strcmp(env, "plain") ? 2 : !strcmp(env, "finegrained") ? 1 : 0) : 0;
+    void *p = nullptr;
+    for (int kind = first; kind < 3; ++kind) {
+        hipError_t e = kind == 0 ? hipExtMallocWithFlags(&p, s->cl.bytes, hipDeviceMallocUncached)
+                     : kind == 1 ? hipExtMallocWithFlags(&p, s->cl.bytes, hipDeviceMallocFinegrained)
+                                 : hipMalloc(&p, s->cl.bytes);
+        if (e == hipSuccess && p) { s->cl.mem_kind = kind; break; }
+        (void)hipGetLastError();
+        p = nullptr;
+    }
+    if (!p) { set_error("cluster: cannot allocate the %zu-byte mirror", s->cl.bytes); return GATO_EHIP; }
+    s->cl.local = (unsigned long long *)p;
+    GATO_HIP_CHECK(hipMemset(p, 0, s->cl.bytes));
+    GATO_HIP_CHECK(hipDeviceSynchronize());
+    return GATO_OK;
+}
+
+extern "C" int gato_cluster_knot_range(int K, int rank, int nranks, int *k0, int *k1)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks || K < nranks) {
+        set_error("cluster: cannot shard %d knots over %d ranks (rank %d)", K, nranks, rank);
+        return GATO_EINVAL;
+    }
+    const int base = K / nranks, extra = K % nranks;           // balanced contiguous ranges, as dist.knot_ranges
+    *k0 = rank * base + (rank < extra ? rank : extra);
+    *k1 = *k0 + base + (rank < extra ? 1 : 0);
+    return GATO_OK;
+}
+
+extern "C" int gato_cluster_create(gato_solver *s, int rank, int nranks, void *ipc_handle_out)
+{
+    if (s->d.B != 1 || nranks > GATO_MAX_RANKS) {
+        set_error("cluster: one system per solver, at most %d ranks", GATO_MAX_RANKS);
+        return GATO_EINVAL;
+    }
+    int k0, k1, rc;
+    if ((rc = gato_cluster_knot_range(s->d.K, rank, nranks, &k0, &k1))) return rc;
+    GATO_HIP_CHECK(hipSetDevice(s->device));
+    gato_cluster_destroy(s);
+    memset(&s->cl, 0, sizeof(s->cl));
+    s->cl.rank = rank; s->cl.nranks = nranks; s->cl.k0 = k0; s->cl.k1 = k1;
+    const size_t need = (size_t)2 * pcg_xslot_granules(s->d.S, (int)s->esz) * 8;
+    s->cl.bytes = need < 65536 ? 65536 : align_up(need, 65536);
+    if ((rc = cluster_alloc(s))) return rc;
+    s->cl.peer[rank] = s->cl.local;
+    if (ipc_handle_out) {
+        hipIpcMemHandle_t h;
+        GATO_HIP_CHECK(hipIpcGetMemHandle(&h, s->cl.local));
+        static_assert(sizeof(h) == 64, "ipc handle size");
+        memcpy(ipc_handle_out, &h, sizeof(h));
+    }
+    return GATO_OK;
+}
+
+extern "C" void *gato_cluster_local_mirror(gato_solver *s) { return s->cl.local; }
+
+// handles: nranks x 64 bytes in rank order (other processes' mirrors are opened through them), and / or ptrs: mirrors
+// that are plain device pointers in THIS process (ranks living in one process).  After this call and BEFORE the first
+// gato_cluster_pcg every rank must pass a host-level barrier (torch.distributed.barrier): the mirrors are zeroed here.
+extern "C" int gato_cluster_connect(gato_solver *s, const void *ipc_handles, void *const *ptrs)
+{
+    if (!s->cl.local) { set_error("cluster_connect: gato_cluster_create first"); return GATO_EINVAL; }
+    GATO_HIP_CHECK(hipSetDevice(s->device));
+    for (int r = 0; r < s->cl.nranks; ++r) {
+        if (r == s->cl.rank) continue;
+        if (ptrs && ptrs[r]) { s->cl.peer[r] = (unsigned long long *)ptrs[r]; continue; }
+        if (!ipc_handles) { set_error("cluster_connect: no mirror given for rank %d", r); return GATO_EINVAL; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)ipc_handles + (size_t)r * sizeof(h), sizeof(h));
+        void *p = nullptr;
+        GATO_HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        s->cl.peer[r] = (unsigned long long *)p;
+        s->cl.opened[r] = true;
+    }
+    GATO_HIP_CHECK(hipMemcpy(s->cl_tab, s->cl.peer, sizeof(void *) * GATO_MAX_RANKS, hipMemcpyHostToDevice));
+    // fresh epoch spaces on both levels (every rank does the same, then the caller's barrier)
+    GATO_HIP_CHECK(hipMemset(s->cl.local, 0, s->cl.bytes));
+    GATO_HIP_CHECK(hipMemset(s->slots, 0, s->slots_bytes));
+    GATO_HIP_CHECK(hipDeviceSynchronize());
+    s->pcg_epoch = 0;
+    s->cl.xepoch = 0;
+    s->cl.on = 1;
+    return GATO_OK;
+}
+
+extern "C" int gato_cluster_destroy(gato_solver *s)
+{
+    if (!s) return GATO_OK;
+    for (int r = 0; r < GATO_MAX_RANKS; ++r)
+        if (s->cl.opened[r] && s->cl.peer[r]) (void)hipIpcCloseMemHandle(s->cl.peer[r]);
+    if (s->cl.local) (void)hipFree(s->cl.local);
+    memset(&s->cl, 0, sizeof(s->cl));
+    return GATO_OK;
+}
+
+// One rank's part of a PCG solve sharded over the cluster: d_S / d_Pinv / d_gamma / d_lambda are FULL-system arrays
+// (block row 0 first) of which this rank reads / writes the rows of its range only.  Every rank must call it with the
+// same exit_tol and max_iters; the launches synchronise with each other on the device (bounded spins), never on the
+// host.  d_iters: as gato_pcg (-1 = a hand-off timed out).  d_lambda holds this rank's slice on return.
+extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
+                                double exit_tol, int max_iters, int *d_iters, void *stream)
+{
+    if (!s->cl.on) { set_error("cluster_pcg: gato_cluster_connect first"); return GATO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    int groups = 0, threads = 0, kpw = 0;
+    // geometry over this rank's knots; the one-workgroup special kernels have no cross-GPU level
+    const int np = s->no_pair, nl = s->no_single_lds;
+    s->no_pair = 1; s->no_single_lds = 1;
+    const int fits = plan_resident_k(s, s->cl.k1 - s->cl.k0, &groups, &threads, &kpw);
+    s->no_pair = np; s->no_single_lds = nl;
+    if (!fits) {
+        set_error("cluster_pcg: %d knots per rank do not fit a persistent launch on %d CUs", s->cl.k1 - s->cl.k0, s->num_cus);
+        return GATO_EINVAL;
+    }
+    const unsigned need = max_iters > 0x3FFFFFF0 ? 0x80000000u : 2u * (unsigned)max_iters + 8u;
+    if (s->cl.xepoch > 0xFFFFFFFFu - need - 8u) {
+        set_error("cluster_pcg: epoch space used up - reconnect the cluster (gato_cluster_connect + barrier)");
+        return GATO_EINVAL;
+    }
+    if (s->pcg_epoch > 0xFFFFFFFFu - need - 8u) {
+        GATO_HIP_CHECK(hipMemsetAsync(s->slots, 0, s->slots_bytes, st));
+        s->pcg_epoch = 0;
+    }
+    PcgLaunch a;
+    memset(&a, 0, sizeof(a));
+    a.S_bd = d_S; a.P_bd = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda;
+    a.lambda0 = s->true_warm_start ? d_lambda : nullptr;
+    a.K = s->d.K; a.max_iters = max_iters; a.exit_tol = exit_tol;
+    a.batch = 1; a.semi = s->plan_semi;
+    a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
+    a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
+    a.epoch0 = s->pcg_epoch; s->pcg_epoch += need;
+    a.xepoch0 = s->cl.xepoch; s->cl.xepoch += need;
+    if (++s->pcg_launch_id <= 0) s->pcg_launch_id = 1;
+    a.launch_id = s->pcg_launch_id;
+    a.final_eta = s->final_eta;
+    a.eta_hist = (s->record_eta && max_iters <= GATO_ETA_HIST_MAX) ? s->eta_hist : nullptr;
+    a.timeout_ticks = (unsigned long long)s->timeout_ms * 100000ull;
+    a.k_begin = s->cl.k0; a.k_end = s->cl.k1; a.rank = s->cl.rank; a.nranks = s->cl.nranks;
+    a.xslots = s->cl.local;
+    a.xpeer = s->cl_tab;
+    a.ev_start = s->time_pcg ? s->ev_pcg0 : nullptr;
+    a.ev_stop = s->time_pcg ? s->ev_pcg1 : nullptr;
+    s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT; s->last_variant = 0;
+    s->last_semi = a.semi; s->last_stream = st;
+    // the launches of a cluster wait for EACH OTHER: they are never queued behind one another (ranks sharing a device
+    // exist in tests only), but they count for the other launches of this process
+    int rc;
+    if ((rc = s->ops->pcg_resident(a, st))) return rc;
+    return gate_after(s->device, groups, st);
 }

@@ -19,6 +19,8 @@
 // common robot sizes
 #define GATO_SHAPES(X) X(2, 1) X(14, 7) X(32, 16) X(4, 2) X(6, 3) X(12, 6) GATO_EXTRA_SHAPES(X)
 
+#define GATO_MAX_RANKS 8     /* GPUs of one node a cluster launch spans (gato_cluster_*) */
+
 namespace gato {
 
 void set_error(const char *fmt, ...);
@@ -121,6 +123,14 @@ struct PcgLaunch {
     int semi;                    // 1: semi-resident launch (knots_per_wg exceeds the lanes, the rest are extra rows); 2: no resident rows
     unsigned long long *slots;   // hand-off granules: every 8-byte word {epoch, payload}; epochs only grow, so no re-zeroing
     unsigned epoch0;             // this launch uses epochs epoch0+1 .. (the solver hands out disjoint ranges)
+    // knot range [k_begin, k_end) of the system this launch works on (single GPU: 0, K).  Multi-GPU cluster launch
+    // (gato_cluster_pcg): rank r of nranks runs this kernel on ITS range; K stays the global knot count, S_bd / P_bd /
+    // gamma / lambda are full-system arrays of which only the rows of the range are touched.
+    int k_begin, k_end;
+    int rank, nranks;            // nranks > 1: second hand-off level through the cross-GPU mirrors below
+    unsigned long long *xslots;                    // this rank's mirror (fine-grained memory, written by the peers)
+    unsigned long long *const *xpeer;              // DEVICE table [nranks]: every rank's mirror as mapped into this process (xpeer[rank] == xslots)
+    unsigned xepoch0;            // cross-GPU epochs: in lock-step on all ranks (only cluster launches draw from this counter)
     int launch_id;               // > 0; a timed-out hand-off stores it into *status (stale ids of earlier launches are ignored)
     int *iters;                  // device
     int *status;                 // device, 0 ok / 1 timeout
@@ -131,6 +141,12 @@ struct PcgLaunch {
     int ablate;                        // diagnostic: timing-only ablation mask (0 in production)
     unsigned long long *stamps;        // optional: diagnostic cycle stamps (16 words), selects the STAMP build
 };
+
+// Cross-GPU mirror of a cluster launch, per epoch parity (granules): one 128-B line per rank for its total (written by
+// that rank's workgroup 0 into EVERY rank's mirror), then the left and the right ghost S-block (written by the
+// neighbouring rank's last / first workgroup).  Every line has exactly one writer.
+__host__ __device__ inline int pcg_xghost_granules(int S, int esz) { return ((S * (esz / 4) + 15) / 16) * 16; }
+__host__ __device__ inline int pcg_xslot_granules(int S, int esz) { return 16 * GATO_MAX_RANKS + 2 * pcg_xghost_granules(S, esz); }
 
 // Granules (8 B: {epoch:32 | payload:32}) per workgroup and parity in the hand-off area.
 // Line 0 (16 granules) holds the partial dot, then first-block and last-block halos.

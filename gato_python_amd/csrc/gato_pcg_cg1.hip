@@ -74,10 +74,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
     const int slotG = pcg_slot_granules_cg1(S, (int)sizeof(T));
     gu64 *slots = (gu64 *)a.slots;
     gi32 *g_status = (gi32 *)a.status;
-    if (tid == 0) {
-        s_abort = 0;
-        if (W == 1 && sys == 0) *a.status = 0;
-    }
+    if (tid == 0) s_abort = 0;
     // r = gamma on knots k0-2 .. k1+1 (zeros outside the system)
     for (int i = tid; i < (nk + 4) * S; i += blockDim.x) {
         const int kk = k0 - 2 + i / S;
@@ -245,7 +242,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
     }
     if (own) dL[(size_t)k * S + r_] = lam;
     if (wg == 0 && tid == 0) {
-        a.iters[sys] = iters;
+        a.iters[sys] = aborted ? -1 : iters;
         if (a.final_eta && sys == 0) *a.final_eta = (double)gamma_new;
     }
 }

@@ -19,42 +19,32 @@ template <typename T>
 __device__ __forceinline__ T wave_sum(T v) { return wave_sum_dpp(v); }
 
 // ---- granule transport -------------------------------------------------------------------
-template <typename T> struct Granule;
-template <> struct Granule<float> {
+// SCOPE: __HIP_MEMORY_SCOPE_AGENT for hand-offs between the workgroups of one GPU (sc1 stores / loads),
+// __HIP_MEMORY_SCOPE_SYSTEM for the cross-GPU mirrors of a cluster launch (sc0 sc1: through to memory / the fabric).
+template <typename T, int SCOPE> struct GranuleT;
+template <int SCOPE> struct GranuleT<float, SCOPE> {
     static constexpr int GPV = 1;
     __device__ static __forceinline__ void store(gu64 *g, unsigned ep, float v)
     {
-        __hip_atomic_store(g, ((unsigned long long)ep << 32) | f2u(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g, ((unsigned long long)ep << 32) | f2u(v), __ATOMIC_RELAXED, SCOPE);
     }
     __device__ static __forceinline__ float decode(const unsigned long long (&x)[1]) { return u2f((unsigned)x[0]); }
-    // returns true when the tag matches; value in v
-    __device__ static __forceinline__ bool load(gu64 *g, unsigned ep, float &v)
-    {
-        unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = u2f((unsigned)x);
-        return (unsigned)(x >> 32) == ep;
-    }
 };
-template <> struct Granule<double> {
+template <int SCOPE> struct GranuleT<double, SCOPE> {
     static constexpr int GPV = 2;
     __device__ static __forceinline__ void store(gu64 *g, unsigned ep, double v)
     {
         unsigned long long b = (unsigned long long)__double_as_longlong(v);
-        __hip_atomic_store(g, ((unsigned long long)ep << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(g + 1, ((unsigned long long)ep << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g, ((unsigned long long)ep << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, SCOPE);
+        __hip_atomic_store(g + 1, ((unsigned long long)ep << 32) | (b >> 32), __ATOMIC_RELAXED, SCOPE);
     }
     __device__ static __forceinline__ double decode(const unsigned long long (&x)[2])
     {
         return __longlong_as_double((long long)((x[1] << 32) | (x[0] & 0xffffffffull)));
     }
-    __device__ static __forceinline__ bool load(gu64 *g, unsigned ep, double &v)
-    {
-        unsigned long long lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
-        return (unsigned)(lo >> 32) == ep && (unsigned)(hi >> 32) == ep;
-    }
 };
+template <typename T> using Granule = GranuleT<T, __HIP_MEMORY_SCOPE_AGENT>;
+template <typename T> using GranuleSys = GranuleT<T, __HIP_MEMORY_SCOPE_SYSTEM>;
 
 constexpr int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 

@@ -110,13 +110,27 @@ __device__ __forceinline__ T row_from_memory(const T *__restrict__ src, const T 
 // matrix registers per lane the workgroup can be 2-4x larger (more loads in flight per CU): the variant for shapes whose
 // resident rows leave one wave per SIMD (fp64, S = 32) and for the HBM-bound end of the range.  The boundary blocks the
 // hand-off publishes are then read from the product array in LDS instead of from lane registers.
-template <typename T, int S, int MAXT, int NL = 0, bool STAMP = false, int XR = 0, bool NR = false>
+// MR: cluster launch (gato_cluster_pcg) - this kernel is ONE RANK of a solve whose knots are sharded over the GPUs of a
+// node (the reference is single-device, gato_utils.cuh:831).  The hand-off gets a second level:
+// after the workgroups of this GPU have gathered their partials (level 1, unchanged), workgroup 0 stores the rank's
+// total into EVERY rank's mirror (peer-mapped fine-grained memory: xGMI peer stores, system scope), the rank's first /
+// last workgroup store their boundary block into the left / right neighbour rank's mirror, and wave 0 of every
+// workgroup polls its OWN GPU's mirror until the R totals (and, at the rank's edges, the neighbour's block) carry the
+// epoch; totals are summed in rank order (identical on every rank => identical exit decision).  The grid barriers of
+// the reference (gato_pcg.cuh:363,378,393,428) thus become two device-initiated all-gathers per iteration across the
+// node, no host involvement, no collective library inside the loop.
+template <typename T, int S, int MAXT, int NL = 0, bool STAMP = false, int XR = 0, bool NR = false, bool MR = false>
 __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 {
     typedef ResidentCfg<T, S, MAXT> Cfg;
     typedef Granule<T> Gr;
+    typedef GranuleSys<T> XGr;
     constexpr int SP = Cfg::SP;
     constexpr int GPV = Gr::GPV;
+    // hand-off layout invariant (DESIGN.md 3.1 dead end 2: granules of two writers in one 128-B line get lost across
+    // XCDs): a workgroup's slot is a whole number of 128-B lines (16 granules), the partial has line 0 to itself
+    static_assert(MAXT % 64 == 0 && 2 * S * GPV <= 16 * ((2 * S * GPV + 15) / 16), "slot layout");
+    static_assert(!MR || (NL == 0 && !STAMP), "cluster launches use the plain and the semi-resident variants");
 
     constexpr int MAXKX = NR ? Cfg::MAXK * XR : Cfg::MAXK * (1 + XR);          // local knots incl. the extra ones
     static_assert(NL == 0 || XR == 0, "the LDS-tail variant is single-workgroup only");
@@ -148,8 +162,11 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     if (X > 0 && wg >= W) return;
     const size_t sys = batched ? blockIdx.x : 0;
     const int K = a.K;
-    const int k0 = wg * a.knots_per_wg;
-    const int nk = min(a.knots_per_wg, K - k0);
+    // this launch's knot range: the whole system, or this rank's shard of it (MR)
+    const int k_begin = MR ? a.k_begin : 0, k_end = MR ? a.k_end : K;
+    const int R = MR ? a.nranks : 1;
+    const int k0 = k_begin + wg * a.knots_per_wg;
+    const int nk = min(a.knots_per_wg, k_end - k0);
     const int jl = tid / S;                // the lane's slot
     const int r_ = tid - jl * S;           // row inside the knot
     const int n_res = NR ? 0 : (XR > 0 ? min(nk, (int)blockDim.x / S) : nk);    // knots with lanes of their own
@@ -160,10 +177,15 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // extra rows of this lane: rows q = tid + e * blockDim.x (e < ne) of the knots [xk, xk + n_ext)
     const int n_ext_rows = n_ext * S;
     const int ne = XR > 0 ? (n_ext_rows + (int)blockDim.x - 1) / (int)blockDim.x : 0;      // workgroup-uniform trip count
-    __shared__ T xst[XR > 0 ? 2 : 1][XR > 0 ? XR * MAXT : 1];                               // [lambda | product][row]; r, p: the windows
+    __shared__ T xst[2][XR > 0 ? XR * MAXT : 1];                                            // [lambda | product][row]; r, p: the windows
     const int k = k0 + j;
-    const bool has_left = k0 > 0;
+    const bool has_left = k0 > 0;          // a neighbouring block row exists in the SYSTEM ...
     const bool has_right = k0 + nk < K;
+    const bool loc_left = MR ? wg > 0 : has_left;            // ... and it belongs to a workgroup of this launch,
+    const bool loc_right = MR ? wg < W - 1 : has_right;
+    const bool x_left = MR && wg == 0 && has_left;           // or to the neighbouring rank (another GPU)
+    const bool x_right = MR && wg == W - 1 && has_right;
+    const bool multi = W > 1 || (MR && R > 1);               // ghost blocks exist and travel through the hand-off
 
     const T *__restrict__ dS = static_cast<const T *>(a.S_bd) + sys * 3 * S * S * K;
     const T *__restrict__ dP = static_cast<const T *>(a.P_bd) + sys * 3 * S * S * K;
@@ -192,11 +214,23 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     gu64 *slots = (gu64 *)a.slots;
     gi32 *g_status = (gi32 *)a.status;
     const unsigned long long t_limit = a.timeout_ticks;
-
-    if (tid == 0) {
-        s_abort = 0;
-        if (W == 1 && sys == 0) *a.status = 0;
+    // cross-GPU mirror (MR): granules per parity, ghost block offsets
+    const int xslotG = pcg_xslot_granules(S, (int)sizeof(T));
+    const int xghL = 16 * GATO_MAX_RANKS, xghR = xghL + pcg_xghost_granules(S, (int)sizeof(T));
+    unsigned xepoch = MR ? a.xepoch0 : 0u;
+    // mirrors of the peers, read once from the device table: the neighbouring ranks' (edge blocks) and, in lane r of
+    // wave 0 of workgroup 0, rank r's (the rank total goes to every rank)
+    gu64 *xp_prev = nullptr, *xp_next = nullptr, *xp_lane = nullptr;
+    if constexpr (MR) {
+        if (a.rank > 0) xp_prev = (gu64 *)a.xpeer[a.rank - 1];
+        if (a.rank < R - 1) xp_next = (gu64 *)a.xpeer[a.rank + 1];
+        if (wg == 0 && wave == 0 && lane < R) xp_lane = (gu64 *)a.xpeer[lane];
     }
+
+    if (tid == 0) s_abort = 0;     // the status word is never cleared here: the host matches launch ids (gato_pcg_status)
+    // test hook, diagnostic build only (options stamp_pcg + ablate = 16): the last workgroup never shows up, as if it
+    // had not been scheduled - the others must give up after the time-out and report it
+    if (STAMP && (a.ablate & 16) && W > 1 && wg == W - 1) return;
     for (int i = tid; i < 2 * (MAXKX + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = (T)0;
     __syncthreads();
 
@@ -258,6 +292,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     const int abl = STAMP ? a.ablate : 0;   // diagnostic timing-only switches, compiled out of the production build
     auto allreduce_and_halo = [&](T val, T prod, T &total) {
         ++epoch;
+        if constexpr (MR) ++xepoch;
         if (abl & 4) { total = (T)1 + prod * (T)1e-30; return; }
         const T ws = wave_sum(prod);
         T *wp = wpart[epoch & 1];
@@ -267,14 +302,25 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             if (j == 0) Gr::store(mine + 16 + r_ * GPV, epoch, val);
             if (j == nk - 1) Gr::store(mine + 16 + (S + r_) * GPV, epoch, val);
         }
+        if constexpr (MR && !NR) {          // the rank's edge blocks go straight into the neighbouring GPU's mirror
+            if (active) {
+                if (x_left && j == 0) XGr::store(xp_prev + (size_t)(xepoch & 1) * xslotG + xghR + r_ * GPV, xepoch, val);
+                if (x_right && j == nk - 1) XGr::store(xp_next + (size_t)(xepoch & 1) * xslotG + xghL + r_ * GPV, xepoch, val);
+            }
+        }
         __syncthreads();                                                       // B1
         if constexpr (NR) {                 // boundary blocks of the vector just formed: from the product array (complete after B1)
             if (W > 1) {
                 if (tid < S) Gr::store(mine + 16 + tid * GPV, epoch, xst[1][tid]);
                 else if (tid < 2 * S) Gr::store(mine + 16 + tid * GPV, epoch, xst[1][(nk - 1) * S + (tid - S)]);
             }
+            if constexpr (MR) {
+                if (x_left && tid < S) XGr::store(xp_prev + (size_t)(xepoch & 1) * xslotG + xghR + tid * GPV, xepoch, xst[1][tid]);
+                if (x_right && tid >= S && tid < 2 * S)
+                    XGr::store(xp_next + (size_t)(xepoch & 1) * xslotG + xghL + (tid - S) * GPV, xepoch, xst[1][(nk - 1) * S + (tid - S)]);
+            }
         }
-        if (W == 1) {
+        if (W == 1 && !(MR && R > 1)) {
             // one workgroup: every wave sums the per-wave partials itself (fixed order), no second barrier
             // (one LDS read per lane + a DPP sum: a serial loop over the partials would pay one LDS
             //  round trip per wave)
@@ -283,14 +329,15 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         }
         if (wave == 0) {
             T tot = wave_sum(lane < nwaves ? wp[lane] : (T)0);
-            {
+            bool fail = false;
+            if (W > 1) {
                 if (lane == 0) Gr::store(mine, epoch, tot);
                 // sweep: partials of all workgroups + neighbours' halo blocks.  Every lane issues ALL its loads
                 // back to back from clamped (always valid) addresses and waits once: predicated loads would each
                 // get their own s_waitcnt, i.e. one L2 round trip after the other.
                 gu64 *pbase = slots + (size_t)(epoch & 1) * W * slotG;
-                const bool want_l = has_left && lane < S;
-                const bool want_r = has_right && lane >= 32 && lane < 32 + S;
+                const bool want_l = loc_left && lane < S;
+                const bool want_r = loc_right && lane >= 32 && lane < 32 + S;
                 gu64 *hptr = want_l ? pbase + (size_t)(wg - 1) * slotG + 16 + (S + lane) * GPV
                            : want_r ? pbase + (size_t)(wg + 1) * slotG + 16 + (lane - 32) * GPV
                                     : mine;
@@ -300,7 +347,6 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 const int pm_count = (W + 63) >> 6;           // wave-uniform
                 unsigned long long raw[Cfg::PM][GPV], hraw[GPV];
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                bool fail = false;
                 // Cross-XCD launches: the first poll can never hit (the publishers' stores need a fabric round
                 // trip), and W*W early loads only queue in front of those stores.  ~0.35 us of sleep before the
                 // first poll measured -5..-10 % per iteration for W > 32 and +6 % for one-XCD launches.
@@ -339,18 +385,55 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 for (int m = 0; m < Cfg::PM; ++m)
                     pv[m] = (m < pm_count && lane + 64 * m < W) ? Gr::decode(raw[m]) : (T)0;
                 const T hv = Gr::decode(hraw);
-                if (fail) {
-                    if (lane == 0) {
-                        __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        s_abort = 1;
-                    }
-                }
                 T acc = (T)0;
 #pragma unroll
                 for (int m = 0; m < Cfg::PM; ++m) acc += pv[m];
                 tot = wave_sum(acc);
                 if (lane < S) gh[0][lane] = want_l ? hv : (T)0;
                 if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = want_r ? hv : (T)0;
+            } else {                       // one workgroup on this GPU (cluster launch): the ghosts come from level 2 only
+                if (lane < S) gh[0][lane] = (T)0;
+                if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = (T)0;
+            }
+            if constexpr (MR) {
+                if (R > 1 && !fail) {
+                    // ---- level 2: across the GPUs of the node.  tot = this rank's total (identical in all its workgroups)
+                    const size_t xo = (size_t)(xepoch & 1) * xslotG;
+                    if (wg == 0 && lane < R) XGr::store(xp_lane + xo + a.rank * 16, xepoch, tot);
+                    gu64 *xl = (gu64 *)a.xslots + xo;                     // polls stay on THIS GPU's memory
+                    const bool xw_l = x_left && lane < S;
+                    const bool xw_r = x_right && lane >= 32 && lane < 32 + S;
+                    gu64 *tptr = xl + (size_t)min(lane, R - 1) * 16;
+                    gu64 *xhp = xw_l ? xl + xghL + lane * GPV : xw_r ? xl + xghR + (lane - 32) * GPV : tptr;
+                    unsigned long long traw[GPV], xraw[GPV];
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    for (unsigned spin = 0;; ++spin) {
+#pragma unroll
+                        for (int g = 0; g < GPV; ++g) {
+                            traw[g] = __hip_atomic_load(tptr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            xraw[g] = __hip_atomic_load(xhp + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        bool ok = true;
+#pragma unroll
+                        for (int g = 0; g < GPV; ++g) ok &= (unsigned)(traw[g] >> 32) == xepoch && (unsigned)(xraw[g] >> 32) == xepoch;
+                        if (__all(ok)) break;
+                        if ((spin & 255u) == 255u) {
+                            const bool late = __builtin_amdgcn_s_memrealtime() - t0 > t_limit;
+                            const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
+                            if (late || other) { fail = true; break; }
+                        }
+                    }
+                    tot = wave_sum(lane < R ? XGr::decode(traw) : (T)0);     // rank order, the same tree on every GPU
+                    const T xv = XGr::decode(xraw);
+                    if (xw_l) gh[0][lane] = xv;
+                    if (xw_r) gh[1][lane - 32] = xv;
+                }
+            }
+            if (fail) {
+                if (lane == 0) {
+                    __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_abort = 1;
+                }
             }
             if (lane == 0) bc[epoch & 1] = tot;
         }
@@ -401,7 +484,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             if (tid < S) xst[1][tid] = xs[1][SP + tid];
             else if (tid < 2 * S) xst[1][(nk - 1) * S + (tid - S)] = xs[1][nk * SP + (tid - S)];
         }
-        if (W > 1) {
+        if (multi) {
             T dummy;
             allreduce_and_halo(r, (T)0, dummy);
             if (tid < S) xs[1][tid] = gh[0][tid];
@@ -429,7 +512,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             const int q = tid + e * (int)blockDim.x;
             if (q < n_ext_rows) xs[0][(xk + q / S + 1) * SP + q % S] = xst[1][q];
         }
-        if (W > 1) {
+        if (multi) {
             if (tid < S) xs[0][tid] = gh[0][tid];
             else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = gh[1][tid - S];
         }
@@ -462,7 +545,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                     xs[1][wi] -= alpha * xst[1][q];
                 }
             }
-            if (W > 1) {   // ghost r advances with the neighbours' upsilon blocks
+            if (multi) {   // ghost r advances with the neighbours' upsilon blocks
                 if (tid < S) xs[1][tid] -= alpha * gh[0][tid];
                 else if (tid < 2 * S) xs[1][(nk + 1) * SP + (tid - S)] -= alpha * gh[1][tid - S];
             }
@@ -493,7 +576,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                     xs[0][wi] = xst[1][q] + beta * xs[0][wi];
                 }
             }
-            if (W > 1) {
+            if (multi) {
                 if (tid < S) xs[0][tid] = gh[0][tid] + beta * xs[0][tid];
                 else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = gh[1][tid - S] + beta * xs[0][(nk + 1) * SP + (tid - S)];
             }
@@ -508,7 +591,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         if (q < n_ext_rows) dL[(size_t)(k0 + xk) * S + q] = xst[0][q];
     }
     if (wg == 0 && tid == 0) {
-        a.iters[sys] = iters;
+        a.iters[sys] = aborted ? -1 : iters;      // in-band: a timed-out hand-off is visible without a second call
         if (a.final_eta && sys == 0) *a.final_eta = (double)eta_new;
         if (STAMP && a.stamps) {
             for (int i = 0; i < 8; ++i) a.stamps[i] = seg[i];
@@ -557,7 +640,6 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         }
     }
     for (int i = tid; i < 2 * (MAXK + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = 0.f;
-    if (tid == 0 && sys == 0) *a.status = 0;
     __syncthreads();
 
     auto times_window = [&](const f32x2 (&m)[3 * S], const float *xw) -> f32x2 {
@@ -705,8 +787,19 @@ int pcg_resident_plan(PcgPlan *plan)
 }
 
 template <typename T, int S>
-int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
+int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
 {
+    // cluster launch (one rank of a multi-GPU solve): the MR instantiations, geometry over the rank's knot range
+    const bool mr = a0.xslots != nullptr;
+    PcgLaunch a = a0;
+    if (!mr) { a.k_begin = 0; a.k_end = a.K; a.rank = 0; a.nranks = 1; }
+    const int Kl = a.k_end - a.k_begin;                 // knots this launch works on
+    if (mr && (a.pair || a.batch > 1 || a.xcd_pack || a.stamps || a.nranks < 1 || a.nranks > GATO_MAX_RANKS || a.rank < 0 ||
+               a.rank >= a.nranks || a.k_begin < 0 || Kl < 1 || a.k_end > a.K || (a.rank == 0) != (a.k_begin == 0) ||
+               (a.rank == a.nranks - 1) != (a.k_end == a.K))) {
+        set_error("pcg_resident(cluster): bad shard rank=%d/%d knots [%d,%d) of %d", a.rank, a.nranks, a.k_begin, a.k_end, a.K);
+        return GATO_EINVAL;
+    }
     if constexpr (sizeof(T) == 4 && S % 2 == 0 && PairThreads<S>::v > 0) {
         if (a.pair) {
             constexpr int PT = PairThreads<S>::v;
@@ -725,15 +818,16 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
         if (a.semi == 1) {
             constexpr int XT = SemiThreads<T, S>::v;
             const long long extra_rows = ((long long)a.knots_per_wg - a.threads / S) * S;
-            if (a.batch > 1 || a.threads != XT || a.groups < 2 || a.groups > 256 || a.threads / S < 2 ||
-                extra_rows > (long long)SemiRows<T, S>::v * a.threads || (long long)a.groups * a.knots_per_wg < a.K ||
-                (long long)(a.groups - 1) * a.knots_per_wg >= a.K) {
+            if (a.batch > 1 || a.threads != XT || a.groups < (mr ? 1 : 2) || a.groups > 256 || a.threads / S < 2 ||
+                extra_rows > (long long)SemiRows<T, S>::v * a.threads || (long long)a.groups * a.knots_per_wg < Kl ||
+                (long long)(a.groups - 1) * a.knots_per_wg >= Kl) {
                 set_error("pcg_resident(semi): bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d)", a.K, a.groups,
                           a.knots_per_wg, a.threads);
                 return GATO_EINVAL;
             }
             if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-            hipLaunchKernelGGL((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v>), dim3(a.groups), dim3(a.threads), 0, st, a);
+            if (mr) hipLaunchKernelGGL((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v, false, true>), dim3(a.groups), dim3(a.threads), 0, st, a);
+            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v>), dim3(a.groups), dim3(a.threads), 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;
@@ -742,15 +836,16 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
     if constexpr (NoresThreads<T, S>::v > 0) {
         if (a.semi == 2) {
             constexpr int NT = NoresThreads<T, S>::v, NX = NoresRows<T, S>::v;
-            if (a.batch > 1 || a.threads != NT || a.groups < 2 || a.groups > 256 ||
-                (long long)a.knots_per_wg * S > (long long)NX * NT || (long long)a.groups * a.knots_per_wg < a.K ||
-                (long long)(a.groups - 1) * a.knots_per_wg >= a.K) {
+            if (a.batch > 1 || a.threads != NT || a.groups < (mr ? 1 : 2) || a.groups > 256 ||
+                (long long)a.knots_per_wg * S > (long long)NX * NT || (long long)a.groups * a.knots_per_wg < Kl ||
+                (long long)(a.groups - 1) * a.knots_per_wg >= Kl) {
                 set_error("pcg_resident(no resident rows): bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d)", a.K,
                           a.groups, a.knots_per_wg, a.threads);
                 return GATO_EINVAL;
             }
             if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-            hipLaunchKernelGGL((pcg_resident_kernel<T, S, NT, 0, false, NX, true>), dim3(a.groups), dim3(a.threads), 0, st, a);
+            if (mr) hipLaunchKernelGGL((pcg_resident_kernel<T, S, NT, 0, false, NX, true, true>), dim3(a.groups), dim3(a.threads), 0, st, a);
+            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, NT, 0, false, NX, true>), dim3(a.groups), dim3(a.threads), 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;
@@ -758,15 +853,15 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
     }
     constexpr int MAXT0 = MaxThreads<T, S>::v;
     constexpr int SINGLE_T = SingleCu<T, S>::threads;
-    const bool single_lds = SINGLE_T > MAXT0 && a.groups == 1 && a.threads > MAXT0 && a.threads <= SINGLE_T;
+    const bool single_lds = !mr && SINGLE_T > MAXT0 && a.groups == 1 && a.threads > MAXT0 && a.threads <= SINGLE_T;
     const int MAXT = single_lds ? SINGLE_T : MAXT0;
     if (a.batch > 1 && a.groups != 1) {
         set_error("pcg_resident: a batch needs one workgroup per system");
         return GATO_EINVAL;
     }
     if (a.threads > MAXT || a.threads % 64 != 0 || a.threads < 2 * S || a.knots_per_wg * S > a.threads ||
-        a.groups < 1 || a.groups > 256 || (long long)a.groups * a.knots_per_wg < a.K ||
-        (long long)(a.groups - 1) * a.knots_per_wg >= a.K) {
+        a.groups < 1 || a.groups > 256 || (long long)a.groups * a.knots_per_wg < Kl ||
+        (long long)(a.groups - 1) * a.knots_per_wg >= Kl) {
         set_error("pcg_resident: bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d max=%d)", a.K,
                   a.groups, a.knots_per_wg, a.threads, MAXT);
         return GATO_EINVAL;
@@ -786,7 +881,8 @@ int launch_pcg_resident(const PcgLaunch &a, hipStream_t st)
             return GATO_OK;
         }
     }
-    if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
+    if (mr) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false, 0, false, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
+    else if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
     else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false>), dim3(nblocks), dim3(a.threads), 0, st, a);
     GATO_HIP_CHECK(hipGetLastError());
     if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));

@@ -15,6 +15,13 @@ host reads device data inside the loop: kernels and collectives are only enqueue
 
 ShardedPCG is the orchestration; the arithmetic lives behind a backend object (HipShardBackend: the HIP
 kernels through the C ABI, gato_shard_pcg_* in include/gato_hip.h).
+
+ClusterPCG is the xGMI-native transport and the default of linsys_solve_sharded: ONE persistent launch per rank
+per solve, in which the exchange above happens inside the kernel - every rank stores its {epoch, payload}
+granules straight into the peers' IPC-mapped mirrors (system-scope stores over xGMI) and polls only its own
+(gato_cluster_* in include/gato_hip.h, pcg_resident_kernel<..., MR>).  torch.distributed carries the 64-byte
+IPC handles once and the barrier after connecting; nothing of it runs inside the solve.  The all-gather
+schedule above (two launches + two RCCL collectives per iteration) stays as the portable fallback.
 """
 from __future__ import annotations
 
@@ -173,3 +180,113 @@ def linsys_solve_sharded(sysm, exit_tol, max_iters, dtype=np.float32, device=Non
     lam, iters = ShardedPCG(backend, group).solve(max_iters)
     dz = sol.compute_dz(Gi, Cd, d[6], lam)
     return lam, dz, iters, sol
+
+
+class ClusterPCG:
+    """One rank of the in-kernel cross-GPU PCG (gato_cluster_*).  Create once per (solver, group), then call
+    pcg() for every solve: all ranks must issue the same sequence of calls (the epoch counters run in lock-step)."""
+
+    def __init__(self, solver, rank, nranks, group=None, inprocess_peers=None):
+        from . import _lib
+        self._lib, self.sol = _lib, solver
+        self.rank, self.nranks, self.group = rank, nranks, group
+        L = _lib.lib()
+        k0, k1 = ct.c_int(), ct.c_int()
+        _lib.check(L.gato_cluster_knot_range(solver.K, rank, nranks, ct.byref(k0), ct.byref(k1)))
+        self.k0, self.k1 = k0.value, k1.value
+        self._handle = (ct.c_char * 64)()
+        self._inprocess = inprocess_peers is not None
+        _lib.check(L.gato_cluster_create(solver._h, rank, nranks, None if self._inprocess else self._handle))
+        self.mirror = int(L.gato_cluster_local_mirror(solver._h))
+        if not self._inprocess:
+            self._connect_ipc()
+
+    def _connect_ipc(self):
+        import torch.distributed as dist
+        handles = [None] * self.nranks
+        dist.all_gather_object(handles, bytes(self._handle.raw), group=self.group)
+        buf = b"".join(handles)
+        assert len(buf) == 64 * self.nranks
+        self._lib.check(self._lib.lib().gato_cluster_connect(self.sol._h, buf, None))
+        dist.barrier(group=self.group)            # every mirror is zeroed and mapped before anyone launches
+
+    @staticmethod
+    def connect_inprocess(clusters):
+        """Ranks living in ONE process (tests on one GPU, or a single-process multi-GPU host): plain device pointers."""
+        n = len(clusters)
+        arr = (ct.c_void_p * n)(*[c.mirror for c in clusters])
+        for c in clusters:
+            c._lib.check(c._lib.lib().gato_cluster_connect(c.sol._h, None, arr))
+
+    def pcg(self, Sb, Pb, gamma, exit_tol, max_iters, lam, iters, stream=None):
+        """Enqueue this rank's launch.  lam: full-length S*K buffer, this rank's slice is written."""
+        st = self.sol._stream() if stream is None else ct.c_void_p(stream)
+        p = lambda t: ct.c_void_p(t.data_ptr())
+        self._lib.check(self._lib.lib().gato_cluster_pcg(self.sol._h, p(Sb), p(Pb), p(gamma), p(lam), float(exit_tol),
+                                                         int(max_iters), p(iters), st))
+
+    def close(self):
+        if self.sol is not None and self.sol._h:
+            self._lib.lib().gato_cluster_destroy(self.sol._h)
+        self.sol = None
+
+
+_LOCKSTEP_STREAMS = []
+
+
+def lockstep_streams(R):
+    """R streams of this process, always the same ones.  Kernels of one process overlap only if their streams sit on
+    different hardware queues; HIP has GPU_MAX_HW_QUEUES of them per process (default 4: more than 3 in-process ranks
+    need it raised before HIP starts - tests/conftest.py does; one process per GPU, the product configuration, does
+    not care)."""
+    import torch
+    while len(_LOCKSTEP_STREAMS) < R:
+        _LOCKSTEP_STREAMS.append(torch.cuda.Stream())
+    return _LOCKSTEP_STREAMS[:R]
+
+
+def run_cluster_lockstep(solvers, Sb, Pb, gamma, exit_tol, max_iters):
+    """R ranks of a cluster solve in ONE process on one GPU, each on its own stream (the launches must overlap: they
+    wait for each other on the device).  Returns (lambda, [iters per rank])."""
+    import torch
+    R = len(solvers)
+    cl = [ClusterPCG(s_, r, R, inprocess_peers=True) for r, s_ in enumerate(solvers)]
+    ClusterPCG.connect_inprocess(cl)
+    torch.cuda.synchronize()
+    dev = Sb.device
+    lam = torch.zeros(solvers[0].S * solvers[0].K, dtype=Sb.dtype, device=dev)
+    its = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(R)]
+    streams = lockstep_streams(R)
+    torch.cuda.synchronize()
+    for r in range(R):
+        cl[r].pcg(Sb, Pb, gamma, exit_tol, max_iters, lam, its[r], stream=streams[r].cuda_stream)
+    torch.cuda.synchronize()
+    out = [int(i.cpu()[0]) for i in its]
+    for c in cl:
+        c.close()
+    return lam, out
+
+
+def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None, state=None):
+    """Whole solve with the PCG sharded over the ranks of `group` through the in-kernel xGMI hand-off.  Assembly is
+    replicated (one-off O(K), needs no exchange), each rank's launch solves its knot range, lambda is assembled by one
+    sum-all-reduce of the disjoint slices per solve (outside the iteration loop), dz is computed redundantly.
+    `state` (returned as the last element) carries solver, device inputs and the connected cluster across calls."""
+    import torch
+    import torch.distributed as dist
+    from .solver import Solver
+    rank, nranks = dist.get_rank(group), dist.get_world_size(group)
+    if state is None:
+        dev = torch.cuda.current_device() if device is None else device
+        sol = Solver(sysm.S, sysm.C, sysm.K, dtype, dev)
+        state = dict(sol=sol, d=sol.upload_system(sysm), cl=ClusterPCG(sol, rank, nranks, group))
+    sol, d, cl = state["sol"], state["d"], state["cl"]
+    Gd, Cd = sol.convert(*d[:6], sysm.rho)
+    Sb, Pb, gam, Gi = sol.form_schur(Gd, Cd, d[6], d[7])
+    sol.form_ss(Sb, Pb)
+    lam = torch.zeros(sol.S * sol.K, dtype=sol.dtype, device=Sb.device)
+    iters = torch.zeros(1, dtype=torch.int32, device=Sb.device)
+    cl.pcg(Sb, Pb, gam, exit_tol, max_iters, lam, iters)
+    dist.all_reduce(lam, op=dist.ReduceOp.SUM, group=group)
+    dz = sol.compute_dz(Gi, Cd, d[6], lam)
+    return lam, dz, iters, state

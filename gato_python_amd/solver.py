@@ -184,7 +184,15 @@ class Solver:
         return np.frombuffer(buf, dtype=np.float64).copy()
 
     def check_status(self):
+        """Raises GatoError(ETIMEOUT) if a hand-off of any PCG launch since the last check timed out."""
         _lib.check(_lib.lib().gato_pcg_status(self._h, None))
+
+    def recover(self) -> bool:
+        """After linsys / linsys_blocks: if a persistent launch timed out (its workgroups were not co-resident), re-run
+        the PCG through the streaming kernels and recompute dz into the same buffers.  True if that happened."""
+        v = ct.c_int()
+        _lib.check(_lib.lib().gato_solver_recover(self._h, ct.byref(v), self._stream()))
+        return bool(v.value)
 
     def upload_system(self, sysm):
         """KKTSystem (host CSR) -> tuple of device tensors in linsys() argument order."""

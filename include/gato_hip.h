@@ -81,7 +81,8 @@ void *gato_solver_buffer(gato_solver *s, int which);
  * asm_mode (whole-solve entries: 0 = auto - convert + Schur + stair as ONE fused launch when K*B <= 2 x CUs, the
  * stage kernels otherwise; 1 = stage kernels; 2 = fused; both give bit-identical buffers), pcg_semi (-1 = auto: K
  * beyond the register file runs as one persistent semi-resident launch; 0 = the streaming kernels), time_pcg (record
- * hipEvents around the PCG launch), no_single_lds / stamp_pcg / stamp_asm / ablate (diagnostics). */
+ * hipEvents around the PCG launch), timeout_ms (bound of every in-kernel spin, default 2000), max_workgroups (CUs a
+ * persistent launch may count on; 0 = all of the device), no_single_lds / stamp_pcg / stamp_asm / ablate (diagnostics). */
 int gato_solver_set_option(gato_solver *s, const char *name, int value);
 int gato_solver_get_option(gato_solver *s, const char *name, int *value);
 
@@ -101,11 +102,22 @@ int gato_form_schur(gato_solver *s, const void *d_G_dense, const void *d_C_dense
 int gato_form_ss(gato_solver *s, const void *d_S, void *d_Pinv, void *stream);
 /* A4-A8  solve_pcg<T> (gato_pcg.cuh:476-567).  lambda is reset to 0 (D5: warm_start is a no-op in
  * the reference, gato_pcg.cuh:303).  d_iters receives the reference's iteration count (index of
- * the iteration that met |eta| < exit_tol, else max_iters; gato_pcg.cuh:311-313,:406-408).
- * Asynchronous on `stream`; gato_pcg_status() after synchronising reports hand-off timeouts. */
+ * the iteration that met |eta| < exit_tol, else max_iters; gato_pcg.cuh:311-313,:406-408; -1 = a hand-off of a
+ * persistent launch timed out, see gato_pcg_status).  Asynchronous on `stream`. */
 int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma,
              void *d_lambda, double exit_tol, int max_iters, int *d_iters, void *stream);
+/* Hand-off time-outs (the workgroups of a persistent launch were not co-resident - the case the reference excludes
+ * with cudaLaunchCooperativeKernel + check_sms, gato_pcg.cuh:502-526, gato_utils.cuh:829-854): the launch writes
+ * iters = -1 (in-band, no second call needed) and the id of the launch into the solver's status word, which no kernel
+ * ever clears.  gato_pcg_status synchronises the stream of the latest PCG launch and returns GATO_ETIMEOUT if ANY
+ * launch timed out since the previous call (*status = 1), else GATO_OK.  Option timeout_ms bounds every spin (2000). */
 int gato_pcg_status(gato_solver *s, int *status);
+/* The fallback: if a persistent launch of the most recent gato_linsys_device / _blocks call timed out, re-run its PCG
+ * through the streaming kernels (no in-launch hand-off, any residency) and recompute dz into the same output buffers -
+ * a slower correct answer instead of an error.  Synchronises `stream`; *recovered = 1 if that happened.  Multi-
+ * workgroup launches of one process never get there by themselves: a launch that does not fit beside those still in
+ * flight on other streams waits for them (per-device CU budget). */
+int gato_solver_recover(gato_solver *s, int *recovered, void *stream);
 /* Device time of the most recent PCG launch(es) of gato_pcg, measured with hipEvents recorded on the
  * launch stream immediately around the kernel launch(es) (the reference times whole solves with
  * cudaEvents, gpu_library.cu:167-187).  Enabled by option "time_pcg" = 1; synchronises on the stop event. */
@@ -179,6 +191,27 @@ int gato_shard_pcg_finish(gato_solver *s, const void *d_recvB_last, void *d_lamb
 /* Host-side convergence poll between iterations (synchronises `stream`): *done = 1 once the exit test has fired.
  * Every rank computes the same sums, so every rank reads the same value. */
 int gato_shard_pcg_done(gato_solver *s, int *done, void *stream);
+
+/* ---- multi-GPU cluster: the persistent PCG launch with a device-initiated cross-GPU hand-off (NEW work, SURVEY.md
+ * section 8e; replaces the reference's grid barriers gato_pcg.cuh:363,378,393,428 across GPUs).  One process per
+ * GPU.  Rank r owns the balanced contiguous knot range gato_cluster_knot_range gives and a MIRROR (a few KB of
+ * fine-grained device memory) that the peers write with system-scope stores over xGMI: per hand-off the rank's total
+ * goes into every rank's mirror and the rank's boundary blocks into the neighbours'; a rank polls only its own
+ * mirror.  Two hand-offs per iteration, no host involvement, no collective library inside the loop.
+ *   gato_cluster_create   allocates and zeroes the mirror, returns its 64-byte hipIpcMemHandle_t in ipc_handle_out
+ *   gato_cluster_connect  ipc_handles = nranks x 64 bytes in rank order (all-gathered by the caller), and / or
+ *                         ptrs[r] = the mirror of a rank living in THIS process (gato_cluster_local_mirror);
+ *                         afterwards every rank must pass a host barrier before the first gato_cluster_pcg
+ *   gato_cluster_pcg      this rank's part of one solve: full-system S / Pinv / gamma / lambda arrays, of which only
+ *                         the rows of the rank's range are read / written; same exit_tol and max_iters on every
+ *                         rank; asynchronous; d_iters as gato_pcg (-1: a hand-off timed out, on every rank alike) */
+int gato_cluster_knot_range(int K, int rank, int nranks, int *k0, int *k1);
+int gato_cluster_create(gato_solver *s, int rank, int nranks, void *ipc_handle_out);
+void *gato_cluster_local_mirror(gato_solver *s);
+int gato_cluster_connect(gato_solver *s, const void *ipc_handles, void *const *ptrs);
+int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
+                     double exit_tol, int max_iters, int *d_iters, void *stream);
+int gato_cluster_destroy(gato_solver *s);
 
 /* ---- direct block input (new): the caller already holds the per-knot blocks in the
  * reference's dense layouts - d_G_blocks as G_dense WITHOUT rho, d_C_blocks as C_dense - so the CSR scatter is

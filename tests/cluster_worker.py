@@ -1,0 +1,63 @@
+"""Worker of tests/test_gpu_cluster.py: one rank of a cluster solve, one PROCESS per rank, all ranks on cuda:0 (a 1-GPU
+box cannot give every rank its own GPU; the code path - IPC-mapped mirrors, system-scope peer stores, a launch per
+process waiting for the other processes' launches on the device - is the one an 8-GPU node runs).  The gloo group
+only carries the IPC handles and the barriers."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gato_python_amd import synth                      # noqa: E402
+from gato_python_amd.dist import ClusterPCG            # noqa: E402
+from gato_python_amd.solver import Solver              # noqa: E402
+from oracle import c_oracle as co                      # noqa: E402
+
+
+def main():
+    S, C, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    dt = np.float64 if sys.argv[4] == "f64" else np.float32
+    tol, mi, repeats = float(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    s = synth.make_system(S, C, K, seed=13)
+    Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
+    Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+    Pb = co.form_ss(Sb, Pb, S, K)
+    lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, tol, mi)
+    sol = Solver(S, C, K, dt)
+    cl = ClusterPCG(sol, rank, world)
+    dS, dP, dg = sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam)
+    f64 = dt == np.float64
+    for rep in range(repeats):
+        lam = torch.zeros(S * K, dtype=sol.dtype, device="cuda:0")
+        iters = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        dist.barrier()
+        cl.pcg(dS, dP, dg, tol, mi, lam, iters)
+        torch.cuda.synchronize()
+        sol.check_status()
+        it = int(iters.cpu()[0])
+        assert abs(it - it_o) <= (0 if f64 else 2), (it, it_o)
+        mine = lam.cpu().numpy()[cl.k0 * S:cl.k1 * S]
+        err = np.abs(mine - lam_o[cl.k0 * S:cl.k1 * S]).max() / np.abs(lam_o).max()
+        assert err < (1e-9 if f64 else 5e-3), err
+        # the slices of all ranks assemble the full solution
+        full = lam.cpu()
+        dist.all_reduce(full)
+        errf = np.abs(full.numpy() - lam_o).max() / np.abs(lam_o).max()
+        assert errf < (1e-9 if f64 else 5e-3), errf
+    mem = sol.get_option("cluster_mem_kind")
+    groups, threads = sol.get_option("last_groups"), sol.get_option("last_threads")
+    dist.barrier()
+    cl.close()
+    sol.close()
+    dist.destroy_process_group()
+    print(f"rank {rank}/{world} ok iters={it} err={errf:.2e} mem_kind={mem} geometry={groups}x{threads}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+"""GPU suite: the in-kernel cross-GPU hand-off of the persistent PCG (gato_cluster_*, pcg_resident_kernel<..., MR>)
+against the oracle.  A 1-GPU box gives every rank the same GPU: ranks are either solvers on separate streams of ONE
+process (mirrors shared as plain pointers) or separate PROCESSES (mirrors shared through hipIpc handles, exactly as
+on a multi-GPU node); in both the launches of all ranks run concurrently and wait for each other on the device."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+from gato_python_amd import _lib, synth                             # noqa: E402
+from gato_python_amd.dist import knot_ranges, lockstep_streams, run_cluster_lockstep   # noqa: E402
+from oracle import c_oracle as co                                   # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_blocks(S, C, K, dt, seed=13):
+    s = synth.make_system(S, C, K, seed=seed)
+    Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
+    Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+    return Sb, co.form_ss(Sb, Pb, S, K), gam
+
+
+# (S, C, K, ranks, dtype): one workgroup per rank (level 2 only), many per rank, ragged ranges, 8 ranks, f32,
+# BASELINE configs[3] and configs[4] at full size in f64 (equal iteration count with the oracle)
+@pytest.mark.parametrize("S,C,K,R,dt", [(14, 7, 50, 2, np.float64), (14, 7, 53, 3, np.float64), (2, 1, 9, 4, np.float64),
+                                        (14, 7, 300, 2, np.float32), (32, 16, 100, 3, np.float64),
+                                        (14, 7, 4096, 2, np.float64), (32, 16, 1024, 2, np.float64),
+                                        (14, 7, 4096, 8, np.float32), (14, 7, 4096, 8, np.float64),
+                                        (32, 16, 1024, 8, np.float64)])
+def test_cluster_ranks_in_one_process(S, C, K, R, dt):
+    from gato_python_amd.solver import Solver
+    Sb, Pb, gam = oracle_blocks(S, C, K, dt)
+    f64 = dt == np.float64
+    tol, mi = (1e-9, 150) if f64 else (1e-4, 60)
+    lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, tol, mi)
+    sols = [Solver(S, C, K, dt) for _ in range(R)]
+    dS, dP, dg = sols[0].to_device(Sb), sols[0].to_device(Pb), sols[0].to_device(gam)
+    lam, its = run_cluster_lockstep(sols, dS, dP, dg, tol, mi)
+    for x in sols:
+        x.check_status()
+    assert len(set(its)) == 1 and abs(its[0] - it_o) <= (0 if f64 else 2), (its, it_o)
+    err = np.abs(lam.cpu().numpy() - lam_o).max() / np.abs(lam_o).max()
+    assert err < (1e-9 if f64 else 5e-3), err
+    for x in sols:
+        x.close()
+
+
+def test_cluster_back_to_back_solves_and_fixed_iterations():
+    """Several solves through one connected cluster (lock-step epoch ranges), exit_tol = 0 (exactly max_iters iterations)."""
+    from gato_python_amd.dist import ClusterPCG
+    from gato_python_amd.solver import Solver
+    S, C, K, R, dt = 14, 7, 600, 3, np.float64
+    Sb, Pb, gam = oracle_blocks(S, C, K, dt)
+    lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, 0.0, 25)
+    sols = [Solver(S, C, K, dt) for _ in range(R)]
+    dS, dP, dg = sols[0].to_device(Sb), sols[0].to_device(Pb), sols[0].to_device(gam)
+    cl = [ClusterPCG(s_, r, R, inprocess_peers=True) for r, s_ in enumerate(sols)]
+    ClusterPCG.connect_inprocess(cl)
+    assert [(c.k0, c.k1) for c in cl] == knot_ranges(K, R)
+    streams = lockstep_streams(R)
+    torch.cuda.synchronize()
+    first = None
+    for rep in range(5):
+        lam = torch.zeros(S * K, dtype=torch.float64, device="cuda")
+        its = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(R)]
+        torch.cuda.synchronize()
+        for r in range(R):
+            cl[r].pcg(dS, dP, dg, 0.0, 25, lam, its[r], stream=streams[r].cuda_stream)
+        torch.cuda.synchronize()
+        assert [int(i.cpu()[0]) for i in its] == [25] * R
+        got = lam.cpu().numpy()
+        assert np.abs(got - lam_o).max() / np.abs(lam_o).max() < 1e-9
+        first = got if first is None else first
+        assert np.array_equal(got, first)                  # fixed summation order: bitwise reproducible
+    for s_ in sols:
+        s_.check_status()
+        s_.close()
+
+
+def test_cluster_semi_resident_shards():
+    """Shards beyond the register file (semi-resident launch per rank) against the streaming kernels on one GPU."""
+    from gato_python_amd.solver import Solver
+    S, C, K, R, dt = 14, 7, 30000, 2, np.float32
+    sysm = synth.make_system(S, C, K, seed=3)
+    one = Solver(S, C, K, dt)
+    d = one.upload_system(sysm)
+    Gd, Cd = one.convert(*d[:6], sysm.rho)
+    Sb, Pb, gam, _ = one.form_schur(Gd, Cd, d[6], d[7])
+    one.form_ss(Sb, Pb)
+    one.set_option("pcg_mode", _lib.PCG_STREAMING)
+    lam_s, it_s = one.pcg(Sb, Pb, gam, 1e-4, 60)
+    sols = [Solver(S, C, K, dt) for _ in range(R)]
+    for x in sols:
+        x.set_option("max_workgroups", 120)               # the ranks share ONE GPU here: 2 x 120 workgroups fit its 256 CUs
+    lam, its = run_cluster_lockstep(sols, Sb, Pb, gam, 1e-4, 60)
+    assert sols[0].get_option("last_semi") == 1 and sols[0].get_option("last_groups") <= 120
+    assert len(set(its)) == 1 and abs(its[0] - int(it_s.cpu()[0])) <= 1, (its, it_s)
+    a, b = lam.cpu().numpy(), lam_s.cpu().numpy()
+    assert np.abs(a - b).max() / np.abs(b).max() < 2e-3
+    for x in sols + [one]:
+        x.close()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("S,C,K,dt,world", [(14, 7, 4096, "f64", 2), (32, 16, 1024, "f64", 2), (14, 7, 4096, "f32", 2)])
+def test_cluster_one_process_per_rank_ipc(S, C, K, dt, world):
+    """TWO PROCESSES, mirrors shared by hipIpc handles: BASELINE configs[3] / configs[4] shapes, equal `iters` in f64."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), OMP_NUM_THREADS="4",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    tol, mi = ("1e-9", "150") if dt == "f64" else ("1e-4", "60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
+           os.path.join(ROOT, "tests", "cluster_worker.py"), str(S), str(C), str(K), dt, tol, mi, "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count(" ok iters=") == world, r.stdout[-2000:]

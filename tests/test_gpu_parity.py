@@ -717,3 +717,97 @@ def test_csr_with_unsorted_columns_and_explicit_zeros(dt):
         sol.linsys(*dev, 1e-8, 5, s2.rho)
         assert np.array_equal(sol.read_buffer("G_dense"), Gd_o) and np.array_equal(sol.read_buffer("C_dense"), Cd_o)
     sol.close()
+
+
+def test_thirteen_workgroups_of_64_threads_1000_launches():
+    """The geometry of the one hand-off time-out ever seen on the GPU box (round 1, an uncommitted layout that packed the
+    granules of several workgroups into one 128-B line): 13 workgroups x 64 threads at 14/7/50 f32.  The committed
+    layout gives every workgroup its own lines (static_assert in pcg_resident_kernel + the checks below); 1000 launches,
+    every result bitwise equal to the first, no time-out.  One run - not a loop hunting for a fault."""
+    from gato_python_amd.csrc_layout import slot_granules
+    for S_, esz in ((2, 4), (14, 4), (14, 8), (32, 4), (32, 8), (12, 8)):
+        g = slot_granules(S_, esz)
+        assert g % 16 == 0 and g >= 16 + 2 * S_ * (esz // 4)          # whole 128-B lines, partial line + both halo blocks
+    S, C, K, dt = 14, 7, 50, np.float32
+    s = system(S, C, K, seed=2)
+    Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
+    Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+    Pb = co.form_ss(Sb, Pb, S, K)
+    lam_o, _ = co.pcg(Sb, Pb, gam, S, K, 0.0, 20)
+    sol = make_solver(S, C, K, dt)
+    sol.set_option("pcg_threads", 64)
+    sol.set_option("pcg_groups", 13)
+    dS, dP, dg = sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam)
+    lam = sol.new(S * K)
+    it = sol.new(1, torch.int32)
+    first = None
+    for i in range(1000):
+        sol.pcg(dS, dP, dg, 0.0, 20, lam=lam, iters=it, check=False)
+        if i % 250 == 0 or i == 999:
+            got = host(lam)
+            first = got if first is None else first
+            assert np.array_equal(got, first) and int(host(it)[0]) == 20
+    sol.check_status()
+    assert sol.get_option("last_groups") == 13 and sol.get_option("last_threads") == 64
+    assert rel(first, lam_o) < 2e-3
+    sol.close()
+
+
+def test_three_concurrent_multi_workgroup_solves_on_three_streams():
+    """A12: three 114-workgroup persistent launches of one process on three streams cannot all be co-resident (342
+    workgroups, 256 CUs).  The per-device CU budget makes the third wait for the first two; three correct answers."""
+    S, C, K, dt = 14, 7, 4096, np.float32
+    s = system(S, C, K, seed=4)
+    Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
+    Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+    Pb = co.form_ss(Sb, Pb, S, K)
+    lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, 1e-4, 60)
+    sols = [make_solver(S, C, K, dt) for _ in range(3)]
+    dS, dP, dg = sols[0].to_device(Sb), sols[0].to_device(Pb), sols[0].to_device(gam)
+    from gato_python_amd.dist import lockstep_streams
+    streams = lockstep_streams(3)
+    lams = [sols[0].new(S * K) for _ in range(3)]
+    its = [sols[0].new(1, torch.int32) for _ in range(3)]
+    torch.cuda.synchronize()
+    for rep in range(10):
+        for i in range(3):
+            with torch.cuda.stream(streams[i]):
+                sols[i].pcg(dS, dP, dg, 1e-4, 60, lam=lams[i], iters=its[i], check=False)
+    torch.cuda.synchronize()
+    for i in range(3):
+        sols[i].check_status()
+        assert sols[i].get_option("last_groups") > 100
+        assert abs(int(host(its[i])[0]) - it_o) <= 2
+        assert rel(host(lams[i]), lam_o) < 5e-3
+        sols[i].close()
+
+
+def test_handoff_timeout_is_reported_in_band_and_recovered():
+    """A workgroup of a persistent launch that never shows up (test hook of the diagnostic build: the last workgroup
+    returns at once, as if it had not been scheduled) makes the others give up after the time-out: iters = -1 in-band,
+    gato_pcg_status reports it once, and gato_solver_recover re-runs the solve through the streaming kernels."""
+    S, C, K, dt = 14, 7, 512, np.float64
+    s = system(S, C, K, seed=6)
+    lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, 1e-9, 150, s.rho, dtype=dt)
+    sol = make_solver(S, C, K, dt)
+    dev = sol.upload_system(s)
+    lam, dz = sol.new(S * K), sol.new(sol.N)
+    sol.set_option("timeout_ms", 20)
+    sol.set_option("stamp_pcg", 1)
+    sol.set_option("ablate", 16)
+    sol.linsys(*dev, 1e-9, 150, s.rho, lam, dz)
+    assert np.frombuffer(_read_iters(sol), np.int32)[0] == -1
+    with pytest.raises(_lib.GatoError, match="ETIMEOUT"):
+        sol.check_status()
+    sol.check_status()                                    # reported once
+    sol.linsys(*dev, 1e-9, 150, s.rho, lam, dz)           # times out again ...
+    assert sol.recover() is True                          # ... and is re-run through the streaming kernels
+    assert sol.get_option("last_fallback") == 1 and sol.get_option("last_mode") == _lib.PCG_STREAMING
+    assert np.frombuffer(_read_iters(sol), np.int32)[0] == it_o
+    assert rel(host(lam), lam_o) < 1e-9 and rel(host(dz), dz_o) < 1e-9
+    sol.set_option("ablate", 0)
+    sol.set_option("stamp_pcg", 0)
+    sol.linsys(*dev, 1e-9, 150, s.rho, lam, dz)
+    assert sol.recover() is False and sol.get_option("last_mode") == _lib.PCG_RESIDENT
+    assert np.frombuffer(_read_iters(sol), np.int32)[0] == it_o and rel(host(lam), lam_o) < 1e-9
+    sol.close()
