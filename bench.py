@@ -12,10 +12,14 @@ recorded on the launch stream right around it: ALGORITHMIC bytes per iteration
 B_iter = [(6K-4) S^2 + 13 S K] w x iterations / launch time, against 8 TB/s.
 `cpu_baseline` = the C restatement of the same step (oracle/, "port") on the host cores.
 
-N = 1 runs BASELINE.json configs[1] (IIWA 14/7, K = 50, fp64).  N > 1 runs configs[3]: one K = 4096
-system with its knots sharded over the N ranks (RCCL all-gathers of [partial dot | boundary blocks],
-gato_python_amd/dist.py), strong scaling.  `--workload batched_512x_f64` (any N) runs independent batches per rank instead
-(weak scaling, no collective).
+N = 1 runs BASELINE.json configs[1] (IIWA 14/7, K = 50, fp64).  N > 1 (gato_python_amd/dist_bench.py): `value` is
+the same workload on every rank, each rank its own system - "replicas only", no data-path collective (one K = 50 system
+is a single workgroup and cannot shard) - and the knot-sharded solves that do exchange data ride along in the same
+line as "sharded" (configs[3]: K = 4096 split over the ranks) and "sharded_k262144_f32", each with its us/iteration
+beside the same system on one GPU and the transport it ran on (in-kernel xGMI peer stores, or the RCCL fallback).
+`--workload sharded_*` makes a sharded solve the line itself; `--workload batched_512x_f64` (any N) runs independent
+batches per rank (weak scaling, no collective).  `--gpus N` without a torch.distributed.run environment starts the N
+ranks itself.
 """
 from __future__ import annotations
 
@@ -214,8 +218,21 @@ def main():
     ap.add_argument("--pcg-mode", type=int, default=None)
     args = ap.parse_args()
 
-    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started by hand without the launcher: start the N ranks as a child job (nothing has touched the GPU yet) and
+        # pass its exit code on - never a silent one-rank run
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if world > 1 and args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
     if args.gpus > 1 or world > 1 or (args.workload or "").startswith(("sharded", "batched", "replicas")):
         from gato_python_amd import dist_bench
         return dist_bench.main(args)

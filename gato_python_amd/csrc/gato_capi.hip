@@ -1243,6 +1243,27 @@ extern "C" int gato_cluster_destroy(gato_solver *s)
     return GATO_OK;
 }
 
+// Geometry a cluster launch of this rank would use (0 workgroups: the rank's knots do not fit a persistent launch).
+static int cluster_plan(gato_solver *s, int *groups, int *threads, int *kpw)
+{
+    // geometry over this rank's knots; the one-workgroup special kernels have no cross-GPU level
+    const int np = s->no_pair, nl = s->no_single_lds;
+    s->no_pair = 1; s->no_single_lds = 1;
+    const int fits = plan_resident_k(s, s->cl.k1 - s->cl.k0, groups, threads, kpw);
+    s->no_pair = np; s->no_single_lds = nl;
+    return fits;
+}
+
+extern "C" int gato_cluster_fits(gato_solver *s, int *groups, int *threads)
+{
+    if (!s->cl.local) { set_error("cluster_fits: gato_cluster_create first"); return GATO_EINVAL; }
+    int g = 0, t = 0, k = 0;
+    if (!cluster_plan(s, &g, &t, &k)) g = t = 0;
+    if (groups) *groups = g;
+    if (threads) *threads = t;
+    return GATO_OK;
+}
+
 // One rank's part of a PCG solve sharded over the cluster: d_S / d_Pinv / d_gamma / d_lambda are FULL-system arrays
 // (block row 0 first) of which this rank reads / writes the rows of its range only.  Every rank must call it with the
 // same exit_tol and max_iters; the launches synchronise with each other on the device (bounded spins), never on the
@@ -1253,11 +1274,7 @@ extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_P
     if (!s->cl.on) { set_error("cluster_pcg: gato_cluster_connect first"); return GATO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     int groups = 0, threads = 0, kpw = 0;
-    // geometry over this rank's knots; the one-workgroup special kernels have no cross-GPU level
-    const int np = s->no_pair, nl = s->no_single_lds;
-    s->no_pair = 1; s->no_single_lds = 1;
-    const int fits = plan_resident_k(s, s->cl.k1 - s->cl.k0, &groups, &threads, &kpw);
-    s->no_pair = np; s->no_single_lds = nl;
+    const int fits = cluster_plan(s, &groups, &threads, &kpw);
     if (!fits) {
         set_error("cluster_pcg: %d knots per rank do not fit a persistent launch on %d CUs", s->cl.k1 - s->cl.k0, s->num_cus);
         return GATO_EINVAL;

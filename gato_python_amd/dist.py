@@ -58,6 +58,11 @@ class ShardedPCG:
         self.group = group
 
     def _gather(self, out, send):
+        if getattr(send, "is_cuda", False) and self.dist.get_backend(self.group) != "nccl":
+            ho, hs = out.cpu(), send.cpu()                  # one-GPU rehearsals over gloo: through host memory
+            self.dist.all_gather_into_tensor(ho, hs, group=self.group)
+            out.copy_(ho)
+            return
         self.dist.all_gather_into_tensor(out, send, group=self.group)
 
     def solve(self, max_iters: int, check_every: int = 0):
@@ -75,7 +80,10 @@ class ShardedPCG:
             if check_every and (it + 1) % check_every == 0 and b.done():
                 break          # every rank sees the same flag: the sums are identical on all ranks
         lam, iters = b.finish(recvB[max_iters % 3])
-        self.dist.all_reduce(lam, op=self.dist.ReduceOp.SUM, group=self.group)   # slices are disjoint, rest is 0
+        if getattr(lam, "is_cuda", False):
+            allreduce_sum_(lam, self.group)                                          # slices are disjoint, rest is 0
+        else:
+            self.dist.all_reduce(lam, op=self.dist.ReduceOp.SUM, group=self.group)
         return lam, iters
 
 
@@ -182,6 +190,33 @@ def linsys_solve_sharded(sysm, exit_tol, max_iters, dtype=np.float32, device=Non
     return lam, dz, iters, sol
 
 
+class ClusterUnavailable(RuntimeError):
+    """Raised on EVERY rank alike when some rank could not allocate, export or map a mirror (callers fall back to the
+    all-gather schedule over RCCL)."""
+
+
+def _all_ranks_ok(ok: bool, group=None) -> bool:
+    """Logical AND over the ranks (and a barrier), on whatever device the backend of `group` moves."""
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.cpu()[0]))
+
+
+def allreduce_sum_(t, group=None):
+    """In-place sum of a device tensor over the ranks (through host memory when the backend is gloo)."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    else:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    return t
+
+
 class ClusterPCG:
     """One rank of the in-kernel cross-GPU PCG (gato_cluster_*).  Create once per (solver, group), then call
     pcg() for every solve: all ranks must issue the same sequence of calls (the epoch counters run in lock-step)."""
@@ -196,19 +231,39 @@ class ClusterPCG:
         self.k0, self.k1 = k0.value, k1.value
         self._handle = (ct.c_char * 64)()
         self._inprocess = inprocess_peers is not None
-        _lib.check(L.gato_cluster_create(solver._h, rank, nranks, None if self._inprocess else self._handle))
-        self.mirror = int(L.gato_cluster_local_mirror(solver._h))
-        if not self._inprocess:
+        if self._inprocess:
+            _lib.check(L.gato_cluster_create(solver._h, rank, nranks, None))
+        else:
             self._connect_ipc()
+        self.mirror = int(L.gato_cluster_local_mirror(solver._h))
 
     def _connect_ipc(self):
+        """Collective over the group.  Every step that can fail on one rank only is followed by an AND over the ranks,
+        so that all ranks raise ClusterUnavailable together instead of leaving the others in a collective."""
         import torch.distributed as dist
+        L, err = self._lib.lib(), ""
+        try:
+            self._lib.check(L.gato_cluster_create(self.sol._h, self.rank, self.nranks, self._handle))
+        except Exception as e:        # noqa: BLE001
+            err = f"create: {e}"
         handles = [None] * self.nranks
-        dist.all_gather_object(handles, bytes(self._handle.raw), group=self.group)
-        buf = b"".join(handles)
-        assert len(buf) == 64 * self.nranks
-        self._lib.check(self._lib.lib().gato_cluster_connect(self.sol._h, buf, None))
-        dist.barrier(group=self.group)            # every mirror is zeroed and mapped before anyone launches
+        dist.all_gather_object(handles, bytes(self._handle.raw) if not err else b"", group=self.group)
+        if not err and all(len(h) == 64 for h in handles):
+            try:
+                self._lib.check(L.gato_cluster_connect(self.sol._h, b"".join(handles), None))
+            except Exception as e:    # noqa: BLE001
+                err = f"connect: {e}"
+        elif not err:
+            err = "a peer could not export its mirror"
+        if not err:                   # every rank's knots must fit a persistent launch on its GPU
+            g = ct.c_int()
+            L.gato_cluster_fits(self.sol._h, ct.byref(g), None)
+            if g.value == 0:
+                err = f"{self.sol.K} knots over {self.nranks} ranks do not fit one persistent launch per GPU"
+        # AND + barrier: every mirror is zeroed and mapped before anyone launches
+        if not _all_ranks_ok(not err, self.group):
+            L.gato_cluster_destroy(self.sol._h)
+            raise ClusterUnavailable(err or "a peer could not map the mirrors")
 
     @staticmethod
     def connect_inprocess(clusters):
@@ -287,6 +342,6 @@ def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=Non
     lam = torch.zeros(sol.S * sol.K, dtype=sol.dtype, device=Sb.device)
     iters = torch.zeros(1, dtype=torch.int32, device=Sb.device)
     cl.pcg(Sb, Pb, gam, exit_tol, max_iters, lam, iters)
-    dist.all_reduce(lam, op=dist.ReduceOp.SUM, group=group)
+    allreduce_sum_(lam, group)
     dz = sol.compute_dz(Gi, Cd, d[6], lam)
     return lam, dz, iters, state

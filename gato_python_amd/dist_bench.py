@@ -2,10 +2,17 @@
 
 Default (--gpus N, no --workload): the N = 1 workload (BASELINE.json configs[1], IIWA 14/7/50 fp64 whole step) on
 every rank, each rank its own system, no data-path collective: weak scaling, value = all ranks' PCG iterations / s,
-directly comparable with the N = 1 line.  The same JSON line carries, as "sharded", the knot-sharded solve of
-configs[3] (IIWA 14/7, K = 4096 split over the ranks, RCCL all-gathers for the CG dots and halos; strong scaling: a
-step = replicated assembly + sharded PCG of exactly 100 iterations + dz) with its parity against the one-GPU result.
+directly comparable with the N = 1 line ("replicas": that shape is one workgroup on one CU, it does not shard).  The
+same JSON line carries, as "sharded", the knot-sharded solves that DO exchange data - configs[3] (IIWA 14/7, K = 4096)
+and K = 262144 (the size where splitting can pay) split over the ranks, strong scaling: a step = replicated assembly +
+sharded PCG of exactly 100 iterations + dz - each with its us per iteration next to the same system on ONE GPU.
+Transport of the sharded PCG: "xgmi" = ONE persistent launch per rank with the dot + halo exchange inside the kernel
+(peer stores into IPC-mapped mirrors, gato_cluster_*); if the mirrors cannot be mapped or the first solve times out,
+"rccl" = two launches + two RCCL all-gathers per iteration (gato_shard_pcg_*).  The line says which one ran.
 --workload sharded_* makes that solve the line itself; --workload batched_* runs 512 systems per rank per call.
+
+GATO_BENCH_ONE_GPU=1 (rehearsal on a 1-GPU box): every rank uses cuda:0, host collectives run over gloo, each rank
+counts on its share of the CUs only.
 """
 from __future__ import annotations
 
@@ -19,6 +26,29 @@ MAX_ITERS = 100
 WORKLOADS = {"sharded_k4096_f32": (14, 7, 4096, np.float32), "sharded_k4096_f64": (14, 7, 4096, np.float64),
              "sharded_s32_k1024_f32": (32, 16, 1024, np.float32),
              "sharded_k262144_f32": (14, 7, 262144, np.float32)}
+ONE_GPU = os.environ.get("GATO_BENCH_ONE_GPU") == "1"
+
+
+def _max_over_ranks(x, torch, dist):
+    t = torch.tensor([x], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _timed(step, steps, warmup, torch, dist):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over the ranks."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    return _max_over_ranks(time.perf_counter() - t0, torch, dist)
 
 
 def main_batched(args, torch, dist, rank, local, world):
@@ -33,21 +63,7 @@ def main_batched(args, torch, dist, rank, local, world):
     dev = sol.upload_batch([base] * B)
     lam, dz = sol.new(B * S * K), sol.new(B * sol.N)
     iters = sol.new(B, torch.int32)
-    step = lambda: sol.linsys_batched(*dev, 0.0, MAX_ITERS, base.rho, lam, dz, iters)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    el = float(el.item())
+    el = _timed(lambda: sol.linsys_batched(*dev, 0.0, MAX_ITERS, base.rho, lam, dz, iters), args.steps, args.warmup, torch, dist)
     if rank == 0:
         val = MAX_ITERS * B * world * args.steps / el
         print(json.dumps({"metric": "PCG iterations/s", "value": val, "unit": "iterations/s", "n_gpus": world,
@@ -62,8 +78,8 @@ def main_batched(args, torch, dist, rank, local, world):
 
 def replicas_leg(args, torch, dist, rank, local, world):
     """Default for --gpus N > 1: bench.py's N = 1 workload (BASELINE configs[1], IIWA 14/7/50 fp64, whole step) on every
-    rank, each rank its own system - independent solves, no data-path collective, weak scaling.  The line is directly
-    comparable with the N = 1 line; the knot-sharded solve of configs[3] rides along as the "sharded" object."""
+    rank, each rank its own system - independent solves, no data-path collective, weak scaling ("replicas only": one
+    K = 50 system is one workgroup on one CU and cannot be split).  Directly comparable with the N = 1 line."""
     from . import synth
     from .solver import Solver
     name = "iiwa_14_7_k50_f64"
@@ -72,22 +88,7 @@ def replicas_leg(args, torch, dist, rank, local, world):
     sol = Solver(S, C, K, dt, local)
     dev = sol.upload_system(sysm)
     lam, dz = sol.new(S * K), sol.new(sol.N)
-    step = lambda: sol.linsys(*dev, 0.0, MAX_ITERS, sysm.rho, lam, dz)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    sol.check_status()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    el = float(el.item())
+    el = _timed(lambda: sol.linsys(*dev, 0.0, MAX_ITERS, sysm.rho, lam, dz), args.steps, args.warmup, torch, dist)
     sol.check_status()
     # dominant kernel on rank 0: the PCG launch between HIP events on its own stream
     sol.set_option("time_pcg", 1)
@@ -109,7 +110,8 @@ def replicas_leg(args, torch, dist, rank, local, world):
             "config": {"workload": name, "baseline_config": cfg, "STATE_SIZE": S, "CONTROL_SIZE": C, "KNOT_POINTS": K,
                        "max_iters": MAX_ITERS, "exit_tol": 0.0,
                        "step": "convert + Schur/stair assembly + PCG(100 iterations) + dz, inputs resident in HBM",
-                       "parallelism": f"{world} independent systems, one per GPU, no data-path collective",
+                       "parallelism": f"replicas only: {world} independent systems, one per GPU, no data-path collective "
+                                      "(the sharded solves with a real exchange are in 'sharded')",
                        "pcg_kernel": "resident", "pcg_workgroups": groups, "pcg_threads": threads},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                          "traffic": None, "kernel": "pcg_resident (rank 0, per GPU)", "launch_ms": pcg_ms,
@@ -118,58 +120,115 @@ def replicas_leg(args, torch, dist, rank, local, world):
 
 def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
     from . import synth
-    from .dist import HipShardBackend, ShardedPCG
+    from .dist import (ClusterPCG, ClusterUnavailable, HipShardBackend, ShardedPCG, _all_ranks_ok, allreduce_sum_)
     from .solver import Solver
     S, C, K, dt = WORKLOADS[name]
     sysm = synth.make_system(S, C, K, seed=0)
     sol = Solver(S, C, K, dt, local)
+    if ONE_GPU:
+        sol.set_option("max_workgroups", max(1, 240 // world))
     d = sol.upload_system(sysm)
+    dev = f"cuda:{local}"
+    want = os.environ.get("GATO_SHARD_TRANSPORT", "xgmi")
+    transport, why, cl = "rccl", "", None
+    if want == "xgmi":
+        try:
+            cl = ClusterPCG(sol, rank, world)
+            transport = "xgmi"
+        except ClusterUnavailable as e:
+            why = f"mirrors unavailable: {e}"[:200]
 
-    def step(tol=0.0):
+    def assemble():
         Gd, Cd = sol.convert(*d[:6], sysm.rho)
         Sb, Pb, gam, Gi = sol.form_schur(Gd, Cd, d[6], d[7])
         sol.form_ss(Sb, Pb)
-        be = HipShardBackend(sol, rank, world, Sb, Pb, gam, tol, MAX_ITERS)
+        return Cd, Sb, Pb, gam, Gi
+
+    def step_xgmi():
+        Cd, Sb, Pb, gam, Gi = assemble()
+        lam = torch.zeros(S * K, dtype=sol.dtype, device=dev)
+        iters = torch.zeros(1, dtype=torch.int32, device=dev)
+        cl.pcg(Sb, Pb, gam, 0.0, MAX_ITERS, lam, iters)
+        allreduce_sum_(lam)                               # once per solve, outside the iteration loop
+        return lam, sol.compute_dz(Gi, Cd, d[6], lam), iters
+
+    def step_rccl():
+        Cd, Sb, Pb, gam, Gi = assemble()
+        be = HipShardBackend(sol, rank, world, Sb, Pb, gam, 0.0, MAX_ITERS)
         lam, iters = ShardedPCG(be).solve(MAX_ITERS)
-        dz = sol.compute_dz(Gi, Cd, d[6], lam)
-        return lam, dz, iters
+        return lam, sol.compute_dz(Gi, Cd, d[6], lam), iters
 
-    for _ in range(warmup):
-        step()
+    if transport == "xgmi":                               # first solve decides: a time-out anywhere sends every rank to RCCL
+        ok = True
+        try:
+            sol.set_option("timeout_ms", 1000)
+            _, _, it0 = step_xgmi()
+            torch.cuda.synchronize()
+            ok = int(it0.cpu()[0]) == MAX_ITERS
+            try:
+                sol.check_status()
+            except Exception:     # noqa: BLE001
+                ok = False
+        except Exception as e:    # noqa: BLE001
+            ok, why = False, f"{type(e).__name__}: {e}"[:200]
+        if not _all_ranks_ok(ok):
+            transport, why = "rccl", why or "the first in-kernel exchange timed out on some rank"
+    step = step_xgmi if transport == "xgmi" else step_rccl
+    el = _timed(lambda: step(), steps, warmup, torch, dist)
+    lam, dz, iters = step()
     torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        lam, dz, iters = step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    el = float(el.item())
+    pcg_us = None
+    if transport == "xgmi":                               # device time of rank 0's launch (it waits for its peers inside)
+        sol.set_option("time_pcg", 1)
+        ms = []
+        for _ in range(5):
+            dist.barrier()
+            step()
+            ms.append(sol.pcg_last_ms())
+        sol.set_option("time_pcg", 0)
+        pcg_us = 1e3 * float(np.mean(ms[1:])) / MAX_ITERS
+    groups, threads, semi = sol.get_option("last_groups"), sol.get_option("last_threads"), sol.get_option("last_semi")
+    mem_kind = sol.get_option("cluster_mem_kind")
 
-    # parity of the sharded result against the single-GPU resident kernel on the same system (rank 0)
+    # the same system on ONE GPU (rank 0), for parity and for the strong-scaling ratio of this very shape
     parity = None
     if rank == 0:
-        lam1, dz1 = sol.new(S * K), sol.new(sol.N)
-        sol.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
-        torch.cuda.synchronize()
-        den = float(lam1.abs().max())
-        # the same system on ONE GPU with the register-resident kernel, timed here so that the strong-scaling ratio of
-        # this line can be read off without comparing against bench.py's N=1 workload (a different shape)
-        for _ in range(3):
-            sol.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n1 = 20
-        for _ in range(n1):
-            sol.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
-        torch.cuda.synchronize()
-        single = MAX_ITERS * n1 / (time.perf_counter() - t1)
-        parity = {"lam_rel_err_vs_single_gpu": float((lam - lam1).abs().max()) / den,
-                  "dz_abs_err_vs_single_gpu": float((dz - dz1).abs().max()), "iters": int(iters.cpu()[0]),
-                  "same_system_on_one_gpu_resident_iters_per_s": single}
+        one = Solver(S, C, K, dt, local)
+        lam1, dz1 = one.new(S * K), one.new(one.N)
+        single = single_us = None
+        try:
+            one.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
+            torch.cuda.synchronize()
+            one.check_status()
+            for _ in range(2):
+                one.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n1 = 10
+            for _ in range(n1):
+                one.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
+            torch.cuda.synchronize()
+            single = MAX_ITERS * n1 / (time.perf_counter() - t1)
+            one.set_option("time_pcg", 1)
+            bufs = [one.buffer_ptr(i) for i in (3, 4, 5)]
+            mm = []
+            for _ in range(4):
+                one.pcg(bufs[0], bufs[1], bufs[2], 0.0, MAX_ITERS, lam=lam1, check=False)
+                mm.append(one.pcg_last_ms())
+            single_us = 1e3 * float(np.mean(mm[1:])) / MAX_ITERS
+            one.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
+            torch.cuda.synchronize()
+            den = float(lam1.abs().max())
+            parity = {"lam_rel_err_vs_single_gpu": float((lam - lam1).abs().max()) / den,
+                      "dz_abs_err_vs_single_gpu": float((dz - dz1).abs().max()), "iters": int(iters.cpu()[0]),
+                      "same_system_on_one_gpu_iters_per_s": single, "same_system_on_one_gpu_pcg_us_per_iter": single_us,
+                      "same_system_on_one_gpu_kernel": {1: "resident", 2: "streaming"}.get(one.get_option("last_mode")) +
+                                                       (" (semi)" if one.get_option("last_semi") else "")}
+        except Exception as e:    # noqa: BLE001
+            parity = {"error": f"{type(e).__name__}: {e}"[:200], "iters": int(iters.cpu()[0])}
+        one.close()
+    if ONE_GPU:
+        dist.barrier()
     out = None
     if rank == 0:
         w = np.dtype(dt).itemsize
@@ -179,15 +238,24 @@ def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
                "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f64" if w == 8 else "f32", "data": "synthetic",
-               "config": {"workload": name, "baseline_config": "configs[3]", "STATE_SIZE": S, "CONTROL_SIZE": C,
-                          "KNOT_POINTS": K, "knots_per_gpu": K // world, "max_iters": MAX_ITERS, "exit_tol": 0.0,
-                          "parallelism": f"knot-sharded x{world}, 2 RCCL all-gathers of (2S+1) scalars per iteration",
-                          "note": "one K = 4096 system split over the ranks (strong scaling); an iteration is bound by "
-                                  "the two collectives' latency, see same_system_on_one_gpu_resident_iters_per_s"},
+               "config": {"workload": name, "baseline_config": "configs[3]" if K == 4096 else "beyond BASELINE: the size where sharding pays",
+                          "STATE_SIZE": S, "CONTROL_SIZE": C, "KNOT_POINTS": K, "knots_per_gpu": K // world,
+                          "max_iters": MAX_ITERS, "exit_tol": 0.0, "transport": transport, "transport_fallback_reason": why,
+                          "mirror_memory": {0: "uncached", 1: "fine-grained", 2: "hipMalloc"}.get(mem_kind),
+                          "pcg_workgroups_per_gpu": groups, "pcg_threads": threads, "semi_resident": bool(semi),
+                          "parallelism": (f"knot-sharded x{world}; xgmi: one persistent launch per GPU, 2 in-kernel exchanges per iteration "
+                                          "(rank totals to every peer, edge blocks to the neighbours, peer stores into IPC-mapped mirrors)"
+                                          if transport == "xgmi" else
+                                          f"knot-sharded x{world}; rccl: 2 launches + 2 RCCL all-gathers of (2S+1) scalars per iteration"),
+                          "one_gpu_rehearsal": ONE_GPU},
+               "pcg_us_per_iter": pcg_us,
                "roofline": {"bound": "hbm", "achieved": b_iter * val / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
                             "frac": b_iter * val / 1e9 / (8000.0 * world), "traffic": None,
-                            "kernel": "stream_step (whole sharded iteration incl. collectives)"},
+                            "kernel": "pcg_resident (cluster launch)" if transport == "xgmi" else "stream_step + all-gathers",
+                            "note": "whole sharded step incl. replicated assembly and dz"},
                "parity": parity}
+    if cl is not None:
+        cl.close()
     sol.close()
     return out
 
@@ -196,12 +264,15 @@ def main(args):
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if ONE_GPU else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if ONE_GPU:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     wl = args.workload or ""
     if wl.startswith("batched"):
         return main_batched(args, torch, dist, rank, local, world)
@@ -209,13 +280,22 @@ def main(args):
         out = sharded_leg(args, torch, dist, rank, local, world, wl, args.steps, args.warmup)
     else:
         out = replicas_leg(args, torch, dist, rank, local, world)
-        try:            # the line above must survive whatever happens in the rider (an error raised on every rank alike)
-            sh = sharded_leg(args, torch, dist, rank, local, world, "sharded_k4096_f32", min(args.steps, 20), min(args.warmup, 3))
-            if rank == 0:
-                out["sharded"] = {k: sh[k] for k in ("value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline", "parity")}
-        except Exception as e:   # noqa: BLE001
-            if rank == 0:
-                out["sharded"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        riders = {}
+        for rider in ("sharded_k4096_f32", "sharded_k262144_f32"):
+            if rider == "sharded_k262144_f32" and world < 2:
+                continue                                          # one GPU runs it through the streaming kernels: not a sharding number
+            try:        # the line above must survive whatever happens in a rider (an error raised on every rank alike)
+                big = rider == "sharded_k262144_f32"
+                sh = sharded_leg(args, torch, dist, rank, local, world, rider, 3 if big else min(args.steps, 20), 1 if big else min(args.warmup, 3))
+                if rank == 0:
+                    riders[rider] = {k: sh[k] for k in ("value", "unit", "ms_per_step", "scaling", "dtype", "config", "pcg_us_per_iter", "roofline", "parity")}
+            except Exception as e:   # noqa: BLE001
+                if rank == 0:
+                    riders[rider] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if rank == 0:
+            out["sharded"] = riders.get("sharded_k4096_f32")
+            if "sharded_k262144_f32" in riders:
+                out["sharded_k262144_f32"] = riders["sharded_k262144_f32"]
     if rank == 0:
         print(json.dumps(out))
     dist.destroy_process_group()

@@ -209,6 +209,9 @@ int gato_cluster_knot_range(int K, int rank, int nranks, int *k0, int *k1);
 int gato_cluster_create(gato_solver *s, int rank, int nranks, void *ipc_handle_out);
 void *gato_cluster_local_mirror(gato_solver *s);
 int gato_cluster_connect(gato_solver *s, const void *ipc_handles, void *const *ptrs);
+/* Workgroups x threads this rank's launch would use; 0 x 0: its knots do not fit one persistent launch on this GPU
+ * (the caller then takes the gato_shard_pcg_* schedule on every rank). */
+int gato_cluster_fits(gato_solver *s, int *groups, int *threads);
 int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
                      double exit_tol, int max_iters, int *d_iters, void *stream);
 int gato_cluster_destroy(gato_solver *s);
