@@ -61,19 +61,48 @@ def dtype_name(dt):
     return "f64" if np.dtype(dt) == np.float64 else "f32"
 
 
-def run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, max_iters=None, variant=0):
+def run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, max_iters=None, variant=0, min_seconds=0.0):
     global MAX_ITERS, PCG_VARIANT
     PCG_VARIANT = variant
     saved = MAX_ITERS
     if max_iters is not None:
         MAX_ITERS = max_iters
     try:
-        return _run_single(name, steps, warmup, torch, pcg_mode, pcg_reps)
+        return _run_single(name, steps, warmup, torch, pcg_mode, pcg_reps, min_seconds)
     finally:
         MAX_ITERS = saved
 
 
-def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20):
+def latency_floor(sol, bufs, lam, production_us):
+    """What bounds a register-resident launch is not HBM but the dependent chain of an iteration.  Measured live with
+    the timing-only switches of the diagnostic kernel build (option `ablate`; the results of these launches are
+    garbage and are not used): the time of the two block-tridiagonal products alone and of the two reductions /
+    hand-offs alone.  Their sum is the floor an iteration could reach if everything else (vector exchange barriers,
+    the scalar tail, the skew between waves) cost nothing."""
+    def us(abl):
+        sol.set_option("ablate", abl)
+        ms = []
+        for i in range(10):
+            sol.pcg(bufs[0], bufs[1], bufs[2], 0.0, MAX_ITERS, lam=lam, check=False)
+            if i >= 2:
+                ms.append(sol.pcg_last_ms())
+        return 1e3 * float(np.median(ms)) / MAX_ITERS
+    try:
+        sol.set_option("stamp_pcg", 1)
+        full, no_spmv, no_red, nothing = us(0), us(3), us(4), us(15)
+    finally:
+        sol.set_option("ablate", 0)
+        sol.set_option("stamp_pcg", 0)
+    spmv, red = max(full - no_spmv, 0.0), max(full - no_red, 0.0)
+    floor = spmv + red
+    return {"us_per_iteration": floor, "products_us": spmv, "reductions_and_handoffs_us": red,
+            "diagnostic_build_full_us": full, "loop_skeleton_us": nothing,
+            "frac_of_floor": floor / production_us if production_us > 0 else None,
+            "method": "live: diagnostic build of the same kernel, ablate = 3 (no products) / 4 (no reductions, no hand-offs) / "
+                      "15 (loop skeleton); floor = products + reductions; frac_of_floor = floor / production us per iteration"}
+
+
+def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, min_seconds=0.0):
     from gato_python_amd import synth
     from gato_python_amd.solver import Solver
     S, C, K, dt, _ = WORKLOADS[name]
@@ -93,11 +122,19 @@ def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20):
         step()
     torch.cuda.synchronize()
     sol.check_status()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt_s = time.perf_counter() - t0
+    # exactly `steps` steps between synchronisations = one block; blocks are repeated until min_seconds of timed work
+    # have accumulated (the driver's --steps 20 is 5 ms of this workload: too thin a sample for one number)
+    dt_s, blocks = 0.0, 0
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt_s += time.perf_counter() - t0
+        blocks += 1
+        if dt_s >= min_seconds or blocks >= 1000:
+            break
+    steps_timed = steps * blocks
     sol.check_status()
 
     # dominant kernel: the PCG launch, HIP events on its stream right around the launch
@@ -114,9 +151,14 @@ def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20):
     sol.set_option("time_pcg", 0)
     pcg_ms = float(np.mean(ms))
     bytes_launch = b_iter(S, K, np.dtype(dt).itemsize) * MAX_ITERS
+    mode = sol.get_option("last_mode")
+    floor = None
+    if mode == 1 and not PCG_VARIANT:
+        floor = latency_floor(sol, bufs, lam, 1e3 * pcg_ms / MAX_ITERS)
     res = dict(
         workload=name, S=S, C=C, K=K, dtype=dtype_name(dt),
-        iters_per_s=MAX_ITERS * steps / dt_s, ms_per_step=1e3 * dt_s / steps,
+        iters_per_s=MAX_ITERS * steps_timed / dt_s, ms_per_step=1e3 * dt_s / steps_timed, timed_steps=steps_timed,
+        latency_floor=floor,
         pcg_launch_ms=pcg_ms, pcg_launch_ms_min=float(np.min(ms)),
         pcg_iters_per_s=MAX_ITERS / (pcg_ms * 1e-3), pcg_us_per_iter=1e3 * pcg_ms / MAX_ITERS,
         pcg_mode={1: "resident", 2: "streaming"}.get(sol.get_option("last_mode")) + (" (semi)" if sol.get_option("last_semi") else ""),
@@ -160,7 +202,8 @@ def run_batched(S, C, K, dt, B, steps, warmup, torch):
              iters_per_s=MAX_ITERS * B * steps / el, ms_per_step=1e3 * el / steps, pcg_launch_ms=pcg_ms,
              pcg_iters_per_s=MAX_ITERS * B / (pcg_ms * 1e-3), pcg_mode="resident, one workgroup per system",
              algorithmic_bytes_per_launch=bytes_launch, achieved_gbs=bytes_launch / (pcg_ms * 1e-3) / 1e9)
-    r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
+    r["bound"] = "latency / issue inside one CU per system (matrices register-resident: HBM bytes per launch = the matrices once)"
+    r["algorithmic_over_hbm_peak"] = r["achieved_gbs"] / HBM_PEAK_GBS     # > 1 = finishes sooner than HBM could stream the matrices per iteration
     sol.close()
     return r
 
@@ -196,15 +239,85 @@ def cpu_baseline(sysm, dt, budget_s=10.0):
     return best
 
 
-def committed_traffic(name):
-    """HBM bytes per PCG launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+def scipy_cg_baseline(sysm, dt):
+    """Secondary CPU sanity baseline: scipy.sparse.linalg.cg on the assembled -S with -Pinv as the
+    preconditioner (both positive definite), same right-hand side, MAX_ITERS iterations."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    from oracle import gato_oracle as o
+    S, C, K = sysm.S, sysm.C, sysm.K
+    out = o.linsys_solve(*sysm.csr_args(), S, C, K, 0.0, 1, sysm.rho, dtype=dt, return_all=True)
+
+    def bd_to_csr(bd):
+        L, M, R = o.unpack_bd(bd, S, K)
+        blocks = [[None] * K for _ in range(K)]
+        for k in range(K):
+            blocks[k][k] = -M[k]
+            if k > 0:
+                blocks[k][k - 1] = -L[k]
+            if k < K - 1:
+                blocks[k][k + 1] = -R[k]
+        return sp.bmat(blocks, format="csr")
+    A, Mi, b = bd_to_csr(out["S"]), bd_to_csr(out["Pinv"]), -out["gamma"]
+    its = [0]
+
+    def cb(_):
+        its[0] += 1
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 2.0:
+        its[0] = 0
+        spl.cg(A, b, rtol=0.0, atol=0.0, maxiter=MAX_ITERS, M=Mi, callback=cb)
+        n += 1
+    el = time.perf_counter() - t0
+    return {"value": its[0] * n / el, "unit": "PCG iterations/s", "cores": 1, "kind": "scipy.sparse.linalg.cg on -S, M = -Pinv (CSR)",
+            "sample": f"{n} runs of {its[0]} iterations in {el:.1f} s"}
+
+
+def committed_traffic(name, res=None):
+    """HBM bytes per PCG launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json) with their provenance, or
+    (None, reason): the entry is refused when the kernel or launch geometry it was collected on is not what ran now."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get(name, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+    if not os.path.exists(p):
+        return None, "profiles/pmc_traffic.json missing"
+    try:
+        import hashlib
+        raw = open(p, "rb").read()
+        blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()        # = git hash-object
+        e = json.loads(raw).get(name)
+    except Exception as ex:       # noqa: BLE001
+        return None, f"unreadable: {ex}"
+    if not e:
+        return None, "no entry for this workload"
+    src = {"file": "profiles/pmc_traffic.json", "git_blob": blob, "kernel": e.get("kernel"), "grid_threads": e.get("grid_threads"),
+           "collected_by": "tools/profile.sh + tools/summarize_profile.py (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+    if res is not None and res.get("pcg_groups"):
+        want = res["pcg_groups"] * res["pcg_threads"]
+        fam = "double" if res["dtype"] == "f64" else "float"
+        k = e.get("kernel", "")
+        if e.get("grid_threads") not in (want, 8 * want):                  # one-XCD launches use an 8x oversubscribed grid
+            return None, f"stale: collected on a grid of {e.get('grid_threads')} threads, this run launched {want}"
+        if ("pcg_single_f32x2" not in k) and (fam + ", " + str(res["S"])) not in k:
+            return None, f"stale: collected on {k}"
+    return e.get("hbm_bytes_per_launch"), src
+
+
+def annotate(r, name=None):
+    """Roofline fields of a sweep entry.  An HBM fraction is printed only where the launch really streams its matrices
+    every iteration (measured HBM bytes >= 70 % of the algorithmic bytes); register-resident launches read them once
+    per LAUNCH, so for them the ratio of measured to algorithmic bytes and the latency floor are what is reported."""
+    t, src = committed_traffic(name or r["workload"], r)
+    r["hbm_bytes_per_launch_pmc"] = t
+    r["traffic_source"] = src
+    ratio = (t / r["algorithmic_bytes_per_launch"]) if t else None
+    r["hbm_traffic_over_algorithmic"] = ratio
+    streams = (ratio is not None and ratio >= 0.7) or "streaming" in str(r.get("pcg_mode", ""))
+    if streams:
+        r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
+        r["bound"] = "hbm"
+    else:
+        r["bound"] = "latency (matrices register-resident: see latency_floor and hbm_traffic_over_algorithmic)"
+    return r
 
 
 def main():
@@ -242,10 +355,12 @@ def main():
     torch.cuda.set_device(0)
     name = args.workload or "iiwa_14_7_k50_f64"
     S, C, K, dt, cfg = WORKLOADS[name]
-    res, sysm = run_single(name, args.steps, args.warmup, torch, args.pcg_mode)
+    res, sysm = run_single(name, args.steps, args.warmup, torch, args.pcg_mode, min_seconds=0.25)
+    traffic, traffic_src = committed_traffic(name, res)
     out = {
         "metric": "PCG iterations/s", "value": res["iters_per_s"], "unit": "iterations/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+        "timed_steps": res["timed_steps"],      # blocks of exactly `steps` steps, repeated until 0.25 s of timed work
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": res["dtype"], "data": "synthetic",
         "config": {"workload": name, "baseline_config": cfg, "STATE_SIZE": S, "CONTROL_SIZE": C, "KNOT_POINTS": K,
@@ -254,7 +369,8 @@ def main():
                    "pcg_kernel": res["pcg_mode"], "pcg_workgroups": res["pcg_groups"],
                    "pcg_threads": res["pcg_threads"]},
         "roofline": {"bound": "hbm", "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": committed_traffic(name),
+                     "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "latency_floor": res["latency_floor"],
                      "kernel": "pcg_" + str(res["pcg_mode"]), "launch_ms": res["pcg_launch_ms"],
                      "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_launch"],
                      "pcg_only_iterations_per_s": res["pcg_iters_per_s"],
@@ -264,6 +380,10 @@ def main():
     }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(sysm, dt)
+        try:
+            out["cpu_baseline"]["secondary"] = scipy_cg_baseline(sysm, dt)
+        except Exception as ex:       # noqa: BLE001
+            out["cpu_baseline"]["secondary"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
     if not args.no_sweep and args.workload is None:
         sweep = []
         for other in ("iiwa_14_7_k50_f32", "iiwa_14_7_k512_f32", "iiwa_14_7_k4096_f32", "iiwa_14_7_k4096_f64",
@@ -272,8 +392,7 @@ def main():
             r2, _ = run_single(other, max(10, args.steps // 10), 3, torch)      # auxiliary entries: best of two short runs
             if r2["iters_per_s"] > r["iters_per_s"]:
                 r = r2
-            r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
-            r["hbm_bytes_per_launch_pmc"] = committed_traffic(other)
+            annotate(r)
             if not args.no_cpu:
                 So, Co, Ko, dto, _ = WORKLOADS[other]
                 from gato_python_amd import synth as _synth
@@ -282,32 +401,28 @@ def main():
         # opt-in single-reduction variant (one hand-off per iteration; rounding differs from the reference recurrence)
         for other in ("iiwa_14_7_k512_f32", "iiwa_14_7_k4096_f32", "s32_c16_k1024_f32"):
             r, _ = run_single(other, max(10, args.steps // 10), 3, torch, variant=1)
+            annotate(r, other + "_single_reduction_variant")
             r["workload"] += "_single_reduction_variant"
-            r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
             sweep.append(r)
         # SURVEY.md 8d run 3: the K=512 system through the STREAMING kernels (matrices re-read every iteration; they fit L2,
         # so the PMC passes show how little of that reaches HBM) beside the register-resident entry above
         r, _ = run_single("iiwa_14_7_k512_f32", max(10, args.steps // 10), 3, torch, pcg_mode=2)
+        annotate(r, "iiwa_14_7_k512_f32_streaming")
         r["workload"] += "_streaming"
-        r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
-        r["hbm_bytes_per_launch_pmc"] = committed_traffic("iiwa_14_7_k512_f32_streaming")
         sweep.append(r)
         # batches of independent systems: throughput mode of the K=50 shape
         sweep.append(run_batched(14, 7, 50, np.float64, 512, 10, 2, torch))
         sweep.append(run_batched(14, 7, 50, np.float32, 512, 10, 2, torch))
         r, _ = run_single("iiwa_14_7_k16384_f32", 5, 2, torch, pcg_reps=5)
-        r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
-        r["hbm_bytes_per_launch_pmc"] = committed_traffic("iiwa_14_7_k16384_f32")
-        sweep.append(r)
+        sweep.append(annotate(r))
         # HBM-bound regime (matrices 1.2 GB): 20 iterations per solve keep the run short.  Auto = the semi-resident
         # persistent launch (one workgroup per CU, 7 % of the block rows in registers, the rest re-read every product);
         # the streaming kernels (two launches per iteration, LDS-DMA tiles) beside it.
         for mode, tag in ((None, ""), (2, "_streaming")):
             r, _ = run_single("iiwa_14_7_k131072_f32", 3, 1, torch, pcg_mode=mode, pcg_reps=5, max_iters=20)
+            annotate(r, "iiwa_14_7_k131072_f32" + tag)
             r["workload"] += tag
-            r["roofline_frac"] = r["achieved_gbs"] / HBM_PEAK_GBS
             r["max_iters"] = 20
-            r["hbm_bytes_per_launch_pmc"] = committed_traffic("iiwa_14_7_k131072_f32" + tag)
             sweep.append(r)
         out["sweep"] = sweep
     print(json.dumps(out))

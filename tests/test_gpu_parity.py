@@ -3,9 +3,9 @@ inputs, against the committed golden fixtures, and - at BASELINE's full sizes - 
 size-independent properties (KKT residuals, determinism, resident == streaming).
 
 Tolerances: CSR scatter is bit-exact.  fp64 stages: 1e-11 relative (same formulas, different
-summation order only in the wave-parallel dots).  fp32 stages: 2e-4 relative on assembled blocks
-(Gauss-Jordan without pivoting amplifies rounding by cond(theta)), PCG compared at a fixed
-iteration count.  BASELINE's bar, ||dz - dz_ref||inf < 1e-6 and lambda within 1e-6 relative, is
+summation order only in the wave-parallel dots).  fp32: measured against the fp64 oracle on the same
+inputs, beside the fp32 oracle's own error (check_f32 below: GPU error <= 2 x oracle error), PCG at a
+fixed iteration count and at the exit test.  BASELINE's bar, ||dz - dz_ref||inf < 1e-6 and lambda within 1e-6 relative, is
 asserted in fp64 against the dense KKT solve.
 """
 import json
@@ -21,6 +21,8 @@ from gato_python_amd import _lib, synth          # noqa: E402
 from oracle import c_oracle as co                # noqa: E402
 from oracle import gato_oracle as o              # noqa: E402
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
@@ -35,6 +37,36 @@ def host(t):
 def _need_gpu():
     assert torch.cuda.is_available(), "GPU suite needs a GPU"
     _lib.lib()                                    # the HIP library must be the thing that runs
+
+
+# ---- fp32 parity, measured instead of assumed ---------------------------------------------------------------------
+# The reference computes in fp32.  An fp32 result is judged against the fp64 oracle run on the SAME
+# (fp32-rounded) inputs: err_gpu = |x_gpu32 - x_64| / |x_64| beside err_oracle = |x_oracle32 - x_64| / |x_64|, the error
+# the reference's own arithmetic makes in the oracle's (= the reference's) accumulation order.  The HIP kernels sum in
+# another order (MFMA tiles, DPP trees, two rows per lane), so the bar is err_gpu <= F32_FACTOR * err_oracle + F32_FLOOR.
+# Every pair is appended to gpurun_out/f32_parity.json (DESIGN.md section 4 quotes the measured maxima).
+F32_FACTOR, F32_FLOOR = 2.0, 5e-6     # floor: ~40 fp32 ulps (the pendulum run iterates past convergence: 5.2e-6 vs 1.4e-6)
+_F32_LOG = []
+
+
+def check_f32(what, gpu, oracle32, truth64, factor=F32_FACTOR, floor=F32_FLOOR):
+    if not (np.all(np.isfinite(truth64)) and np.all(np.isfinite(oracle32))):
+        return
+    eg, eo = rel(np.asarray(gpu, np.float64), truth64), rel(np.asarray(oracle32, np.float64), truth64)
+    _F32_LOG.append(dict(what=what, err_gpu=float(eg), err_oracle=float(eo)))
+    assert eg <= factor * eo + floor, (what, eg, eo)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_f32_log():
+    yield
+    if _F32_LOG:
+        import json
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "f32_parity.json"), "w") as f:
+            json.dump(dict(factor=F32_FACTOR, floor=F32_FLOOR, max_ratio=max(e["err_gpu"] / max(e["err_oracle"], F32_FLOOR) for e in _F32_LOG),
+                           entries=_F32_LOG), f, indent=1)
 
 
 def make_solver(S, C, K, dt):
@@ -67,24 +99,44 @@ def test_every_stage_against_oracle(S, C, K, seed, dq, dt):
     # A2 Schur / block-Jacobi / gamma / inverses
     Sb, Pb, gam, Gi = sol.form_schur(Gd, Cd, dev[6], dev[7])
     Sb_o, Pb_o, gam_o, Gi_o = co.form_schur(Gd_o, Cd_o, s.g, s.c, S, C, K)
-    assert rel(host(Gi), Gi_o) < tol_blk and rel(host(Sb), Sb_o) < tol_blk
-    assert rel(host(Pb), Pb_o) < tol_blk and rel(host(gam), gam_o) < tol_blk
+    tag = f"{S}/{C}/{K} seed {seed}"
+    if f64:
+        assert rel(host(Gi), Gi_o) < tol_blk and rel(host(Sb), Sb_o) < tol_blk
+        assert rel(host(Pb), Pb_o) < tol_blk and rel(host(gam), gam_o) < tol_blk
+    else:                                     # fp32: against the fp64 oracle on the same fp32-rounded inputs
+        g32, c32 = s.g.astype(np.float32).astype(np.float64), s.c.astype(np.float32).astype(np.float64)
+        Sb_t, Pb_t, gam_t, Gi_t = co.form_schur(Gd_o.astype(np.float64), Cd_o.astype(np.float64), g32, c32, S, C, K)
+        for nm, a, b, t in (("Ginv", Gi, Gi_o, Gi_t), ("S", Sb, Sb_o, Sb_t), ("Pinv.main", Pb, Pb_o, Pb_t), ("gamma", gam, gam_o, gam_t)):
+            check_f32(f"schur {nm} {tag}", host(a), b, t)
+        assert rel(host(Sb), Sb_o) < tol_blk                      # and still close to the fp32 oracle itself
     # A3 stair off-diagonals (fed with the oracle's inputs so the stage is isolated)
     Pb2 = sol.form_ss(sol.to_device(Sb_o), sol.to_device(Pb_o))
     Pb2_o = co.form_ss(Sb_o, Pb_o, S, K)
-    assert rel(host(Pb2), Pb2_o) < (1e-12 if f64 else 2e-5)
+    if f64:
+        assert rel(host(Pb2), Pb2_o) < 1e-12
+    else:
+        check_f32(f"stair Pinv {tag}", host(Pb2), Pb2_o, co.form_ss(Sb_o.astype(np.float64), Pb_o.astype(np.float64), S, K))
     # A5 PCG on the oracle's S, Pinv, gamma: fixed iteration count
     n_it = 8
     lam, it = sol.pcg(sol.to_device(Sb_o), sol.to_device(Pb2_o), sol.to_device(gam_o), 0.0, n_it)
     lam_o, it_o = co.pcg(Sb_o, Pb2_o, gam_o, S, K, 0.0, n_it)
     assert int(host(it)[0]) == it_o == n_it
     if np.all(np.isfinite(lam_o)):
-        assert rel(host(lam), lam_o) < (1e-10 if f64 else 2e-3)
+        if f64:
+            assert rel(host(lam), lam_o) < 1e-10
+        else:
+            lam_t, _ = co.pcg(Sb_o.astype(np.float64), Pb2_o.astype(np.float64), gam_o.astype(np.float64), S, K, 0.0, n_it)
+            check_f32(f"pcg {n_it} iterations {tag}", host(lam), lam_o, lam_t)
     # A9 dz on the oracle's lambda
     lam_c, _ = co.pcg(Sb_o, Pb2_o, gam_o, S, K, 1e-8, 200)
     dz = sol.compute_dz(sol.to_device(Gi_o), sol.to_device(Cd_o) if K > 1 else sol.new(1), dev[6], sol.to_device(lam_c))
     dz_o = co.compute_dz(Gi_o, Cd_o, s.g, lam_c, S, C, K)
-    assert rel(host(dz), dz_o) < (1e-12 if f64 else 2e-5)
+    if f64:
+        assert rel(host(dz), dz_o) < 1e-12
+    else:
+        dz_t = co.compute_dz(Gi_o.astype(np.float64), Cd_o.astype(np.float64), s.g.astype(np.float32).astype(np.float64),
+                             lam_c.astype(np.float64), S, C, K)
+        check_f32(f"dz {tag}", host(dz), dz_o, dz_t)
     sol.close()
 
 
@@ -173,13 +225,21 @@ def test_pcg_variants_against_oracle(S, C, K, dt, opts):
     lam, it = sol.pcg(dS, dP, dg, 0.0, 12)
     lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, 0.0, 12)
     assert int(host(it)[0]) == 12
-    assert rel(host(lam), lam_o) < (1e-10 if f64 else 5e-3)
+    tag = f"{S}/{C}/{K} {opts}"
+    S64, P64, g64 = Sb.astype(np.float64), Pb.astype(np.float64), gam.astype(np.float64)
+    if f64:
+        assert rel(host(lam), lam_o) < 1e-10
+    else:                                      # fp32: error against the fp64 iteration on the same matrices
+        check_f32(f"pcg 12 iterations {tag}", host(lam), lam_o, co.pcg(S64, P64, g64, S, K, 0.0, 12)[0])
     # run to tolerance: iteration count of the reference's exit test
     tol = 1e-8 if f64 else 1e-4
     lam, it = sol.pcg(dS, dP, dg, tol, 300)
     lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, tol, 300)
     assert abs(int(host(it)[0]) - it_o) <= (0 if f64 else 2), (int(host(it)[0]), it_o)
-    assert rel(host(lam), lam_o) < (1e-9 if f64 else 5e-3)
+    if f64:
+        assert rel(host(lam), lam_o) < 1e-9
+    else:                                      # both stopped by the same test: error against the converged fp64 solution
+        check_f32(f"pcg to {tol} {tag}", host(lam), lam_o, co.pcg(S64, P64, g64, S, K, 1e-14, 600)[0])
     # deterministic: bitwise identical on a second run
     lam2, it2 = sol.pcg(dS, dP, dg, tol, 300)
     assert torch.equal(lam, lam2) and torch.equal(it, it2)
