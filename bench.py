@@ -95,11 +95,20 @@ def latency_floor(sol, bufs, lam, production_us):
         sol.set_option("stamp_pcg", 0)
     spmv, red = max(full - no_spmv, 0.0), max(full - no_red, 0.0)
     floor = spmv + red
-    return {"us_per_iteration": floor, "products_us": spmv, "reductions_and_handoffs_us": red,
-            "diagnostic_build_full_us": full, "loop_skeleton_us": nothing,
-            "frac_of_floor": floor / production_us if production_us > 0 else None,
-            "method": "live: diagnostic build of the same kernel, ablate = 3 (no products) / 4 (no reductions, no hand-offs) / "
-                      "15 (loop skeleton); floor = products + reductions; frac_of_floor = floor / production us per iteration"}
+    out = {"us_per_iteration": floor, "products_us": spmv, "reductions_and_handoffs_us": red,
+           "diagnostic_build_full_us": full, "loop_skeleton_us": nothing, "production_us_per_iteration": production_us,
+           "frac_of_floor": floor / full if full > 0 else None,
+           "method": "live: diagnostic build of the same kernel (slower than the production build: cycle stamps), ablate = 3 (no "
+                     "products) / 4 (no reductions, no hand-offs) / 15 (loop skeleton); floor = products + reductions; "
+                     "frac_of_floor = floor / full, both in the diagnostic build"}
+    W = sol.get_option("last_groups")
+    if W > 1:
+        # what one all-to-all round of W workgroups costs with no arithmetic at all (tools/micro/pingpong.hip, MI355X)
+        pp = 0.42 if W <= 2 else 0.59 if W <= 15 else 0.84 if W <= 32 else 1.07
+        out["handoff_floor_us"] = pp
+        out["us_per_iteration_with_handoff_floor"] = spmv + 2 * pp
+        out["handoff_floor_source"] = "tools/micro/pingpong.hip all-to-all round, one polling wave per workgroup: 0.42 (W=2) / 0.59 (W=15) / 0.84 (W=29) us on one XCD, 1.03-1.10 us chip-wide"
+    return out
 
 
 def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, min_seconds=0.0):
@@ -148,21 +157,22 @@ def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, min_seco
         v = sol.pcg_last_ms()
         if i >= 3:
             ms.append(v)
-    sol.set_option("time_pcg", 0)
     pcg_ms = float(np.mean(ms))
     bytes_launch = b_iter(S, K, np.dtype(dt).itemsize) * MAX_ITERS
     mode = sol.get_option("last_mode")
+    mode_name = {1: "resident", 2: "streaming"}.get(mode) + (" (semi)" if sol.get_option("last_semi") else "")
+    groups, threads = sol.get_option("last_groups"), sol.get_option("last_threads")
     floor = None
-    if mode == 1 and not PCG_VARIANT:
+    if mode == 1 and not PCG_VARIANT and not sol.get_option("last_pair") and not sol.get_option("last_semi"):   # the diagnostic build: plain pcg_resident_kernel
         floor = latency_floor(sol, bufs, lam, 1e3 * pcg_ms / MAX_ITERS)
+    sol.set_option("time_pcg", 0)
     res = dict(
         workload=name, S=S, C=C, K=K, dtype=dtype_name(dt),
         iters_per_s=MAX_ITERS * steps_timed / dt_s, ms_per_step=1e3 * dt_s / steps_timed, timed_steps=steps_timed,
         latency_floor=floor,
         pcg_launch_ms=pcg_ms, pcg_launch_ms_min=float(np.min(ms)),
         pcg_iters_per_s=MAX_ITERS / (pcg_ms * 1e-3), pcg_us_per_iter=1e3 * pcg_ms / MAX_ITERS,
-        pcg_mode={1: "resident", 2: "streaming"}.get(sol.get_option("last_mode")) + (" (semi)" if sol.get_option("last_semi") else ""),
-        pcg_groups=sol.get_option("last_groups"), pcg_threads=sol.get_option("last_threads"),
+        pcg_mode=mode_name, pcg_groups=groups, pcg_threads=threads,
         algorithmic_bytes_per_launch=bytes_launch,
         achieved_gbs=bytes_launch / (pcg_ms * 1e-3) / 1e9,
     )

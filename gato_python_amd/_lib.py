@@ -15,6 +15,7 @@ _LIB = None
 
 GATO_F32, GATO_F64 = 0, 1
 PCG_AUTO, PCG_RESIDENT, PCG_STREAMING = 0, 1, 2
+PRECON_STAIR, PRECON_BLOCK_JACOBI, PRECON_POINT_JACOBI = 0, 1, 2
 
 ERRORS = {-1: "EINVAL", -2: "ESHAPE", -3: "EHIP", -4: "ENODEV", -5: "ETIMEOUT"}
 
@@ -29,7 +30,7 @@ SYMBOLS = [
     "gato_shard_pcg_init", "gato_shard_pcg_phase_a", "gato_shard_pcg_phase_b", "gato_shard_pcg_finish",
     "gato_shard_pcg_done", "gato_linsys_device_blocks", "gato_release_cache", "gato_solver_recover",
     "gato_cluster_knot_range", "gato_cluster_create", "gato_cluster_local_mirror", "gato_cluster_connect",
-    "gato_cluster_pcg", "gato_cluster_destroy", "gato_cluster_fits",
+    "gato_cluster_pcg", "gato_cluster_destroy", "gato_cluster_fits", "gato_last_stage_ms",
 ]
 
 
@@ -76,6 +77,7 @@ def lib() -> ct.CDLL:
         L.gato_pcg.argtypes = [vp, vp, vp, vp, vp, d, i, vp, vp]
         L.gato_pcg_status.argtypes = [vp, ct.POINTER(ct.c_int)]
         L.gato_pcg_last_ms.argtypes = [vp, ct.POINTER(ct.c_float)]
+        L.gato_last_stage_ms.argtypes = [vp, ct.POINTER(ct.c_float)]
         L.gato_compute_dz.argtypes = [vp] * 7
         L.gato_linsys_device.argtypes = [vp, ip, ip, vp, ip, ip, vp, vp, vp, d, i, d, vp, vp, vp]
         L.gato_infer_shape.argtypes = [ip, i, i, i] + [ct.POINTER(ct.c_int)] * 3

@@ -270,6 +270,22 @@ __global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, c
     }
 }
 
+// ---- point-Jacobi preconditioner: the reference's build with BLOCK_J_PRECON = SS_PRECON = 0 (gato_defines.h:9-10;
+// gato_schur.cuh:424-428): Pinv[k].main = diag(1 / S[k].main_ii), every other entry of the block row zero (the
+// reference leaves them as cudaMalloc returned them; zero is what it means).
+template <typename T, int S>
+__global__ __launch_bounds__(256) void point_jacobi_kernel(const T *__restrict__ Sbd, T *__restrict__ Pbd, int K, BatchStride bs)
+{
+    constexpr int SS = S * S;
+    Sbd += blockIdx.y * bs.bd; Pbd += blockIdx.y * bs.bd;
+    const size_t total = (size_t)3 * SS * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % (3 * SS));
+        const bool diag = w >= SS && w < 2 * SS && (w - SS) % (S + 1) == 0;
+        Pbd[i] = diag ? (T)1 / Sbd[i] : (T)0;
+    }
+}
+
 // ---- A3: symmetric stair (gato_schur.cuh:497-649) ------------------------------------------------
 template <typename T, int S>
 __global__ __launch_bounds__(WAVE) void ss_kernel(const T *__restrict__ Sbd, T *__restrict__ Pbd, int K, BatchStride bs)
@@ -774,6 +790,16 @@ int launch_form_ss(const Dims &d, const T *Sbd, T *Pbd, hipStream_t st)
 }
 
 template <typename T, int S, int C>
+int launch_point_jacobi(const Dims &d, const T *Sbd, T *Pbd, hipStream_t st)
+{
+    const size_t total = d.bd();
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL((point_jacobi_kernel<T, S>), dim3(blocks, d.B), dim3(256), 0, st, Sbd, Pbd, d.K, batch_stride(d));
+    GATO_HIP_CHECK(hipGetLastError());
+    return GATO_OK;
+}
+
+template <typename T, int S, int C>
 int launch_compute_dz(const Dims &d, const T *Ginv, const T *Cd, const T *g, const T *lambda, T *dz,
                       hipStream_t st)
 {
@@ -799,6 +825,8 @@ int launch_compute_dz(const Dims &d, const T *Ginv, const T *Cd, const T *g, con
     template int launch_assemble<float, S_, C_>(const Dims &, const AsmArgs &, hipStream_t);                      \
     template int launch_assemble<double, S_, C_>(const Dims &, const AsmArgs &, hipStream_t);                     \
     template int launch_form_ss<float, S_, C_>(const Dims &, const float *, float *, hipStream_t);               \
+    template int launch_point_jacobi<float, S_, C_>(const Dims &, const float *, float *, hipStream_t);          \
+    template int launch_point_jacobi<double, S_, C_>(const Dims &, const double *, double *, hipStream_t);       \
     template int launch_form_ss<double, S_, C_>(const Dims &, const double *, double *, hipStream_t);            \
     template int launch_compute_dz<float, S_, C_>(const Dims &, const float *, const float *, const float *,     \
                                                   const float *, float *, hipStream_t);                          \

@@ -42,6 +42,9 @@ static Ops make_ops(int dtype)
     o.form_ss = [](const Dims &d, const void *Sb, void *Pb, hipStream_t st) {
         return launch_form_ss<T, S, C>(d, (const T *)Sb, (T *)Pb, st);
     };
+    o.point_jacobi = [](const Dims &d, const void *Sb, void *Pb, hipStream_t st) {
+        return launch_point_jacobi<T, S, C>(d, (const T *)Sb, (T *)Pb, st);
+    };
     o.compute_dz = [](const Dims &d, const void *Gi, const void *Cd, const void *g, const void *lam, void *dz,
                       hipStream_t st) {
         return launch_compute_dz<T, S, C>(d, (const T *)Gi, (const T *)Cd, (const T *)g, (const T *)lam, (T *)dz, st);
@@ -140,6 +143,9 @@ struct gato_solver {
     int status_ack;
     hipStream_t last_stream;          // stream of the most recent PCG launch (gato_pcg_status synchronises it)
     int timeout_ms;                   // option: bound of every in-kernel spin (default 2000)
+    int precon_mode;                  // option: GATO_PRECON_* (whole-solve entries)
+    int time_stages;                  // option: hipEvents around assembly / PCG / dz of the whole-solve entries
+    hipEvent_t ev_stage[4];
     int max_workgroups;               // option: CUs a persistent launch may count on (0 = all; ranks sharing one GPU in tests)
     int last_fallback;                // the most recent gato_solver_recover re-ran the PCG through the streaming kernels
     struct {                          // arguments of the most recent whole solve, for gato_solver_recover
@@ -382,6 +388,8 @@ extern "C" int gato_solver_destroy(gato_solver *s)
     gato_cluster_destroy(s);
     if (s->ev_pcg0) (void)hipEventDestroy(s->ev_pcg0);
     if (s->ev_pcg1) (void)hipEventDestroy(s->ev_pcg1);
+    for (int i = 0; i < 4; ++i)
+        if (s->ev_stage[i]) (void)hipEventDestroy(s->ev_stage[i]);
     if (s->arena) (void)hipFree(s->arena);
     if (s->in_arena) (void)hipFree(s->in_arena);
     if (s->pin) (void)hipHostFree(s->pin);
@@ -426,6 +434,15 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "true_warm_start")) s->true_warm_start = value;
     else if (!strcmp(name, "timeout_ms")) s->timeout_ms = value > 0 ? value : 2000;
     else if (!strcmp(name, "max_workgroups")) s->max_workgroups = value;
+    else if (!strcmp(name, "precon_mode")) {
+        if (value < GATO_PRECON_STAIR || value > GATO_PRECON_POINT_JACOBI) { set_error("precon_mode must be 0, 1 or 2"); return GATO_EINVAL; }
+        s->precon_mode = value;
+    }
+    else if (!strcmp(name, "time_stages")) {
+        s->time_stages = value;
+        if (value && !s->ev_stage[0])
+            for (int i = 0; i < 4; ++i) GATO_HIP_CHECK(hipEventCreate(&s->ev_stage[i]));
+    }
     else if (!strcmp(name, "batch_nnz_G")) s->d.nnzG = value;
     else if (!strcmp(name, "batch_nnz_C")) s->d.nnzC = value;
     else if (!strcmp(name, "time_pcg")) {
@@ -447,6 +464,17 @@ extern "C" int gato_pcg_last_ms(gato_solver *s, float *ms)
     return GATO_OK;
 }
 
+// Stage times of the most recent whole solve as data (the reference prints "Forming Schur took" and the solve time,
+// gato_schur.cuh:907-913,972-982; gpu_library.cu:186-198): ms[0] = CSR scatter + Schur + preconditioner, ms[1] = PCG,
+// ms[2] = dz.  Needs option time_stages = 1; synchronises on the last event.
+extern "C" int gato_last_stage_ms(gato_solver *s, float *ms)
+{
+    if (!s->time_stages || !s->ev_stage[0]) { set_error("last_stage_ms: option time_stages is off"); return GATO_EINVAL; }
+    GATO_HIP_CHECK(hipEventSynchronize(s->ev_stage[3]));
+    for (int i = 0; i < 3; ++i) GATO_HIP_CHECK(hipEventElapsedTime(ms + i, s->ev_stage[i], s->ev_stage[i + 1]));
+    return GATO_OK;
+}
+
 extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *value)
 {
     if (!strcmp(name, "pcg_mode")) *value = s->pcg_mode;
@@ -462,6 +490,7 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "last_semi")) *value = s->last_semi;
     else if (!strcmp(name, "last_fallback")) *value = s->last_fallback;
     else if (!strcmp(name, "timeout_ms")) *value = s->timeout_ms;
+    else if (!strcmp(name, "precon_mode")) *value = s->precon_mode;
     else if (!strcmp(name, "cluster_mem_kind")) *value = s->cl.on ? s->cl.mem_kind : -1;
     else if (!strcmp(name, "num_cus")) *value = s->num_cus;
     else if (!strcmp(name, "batch")) *value = s->d.B;
@@ -769,7 +798,9 @@ static int assemble(gato_solver *s, int mode, const int *G_row, const int *G_col
                     hipStream_t st)
 {
     int rc;
-    const bool fused = s->asm_mode == 2 || (s->asm_mode == 0 && (long long)s->d.K * s->d.B <= 2ll * s->num_cus);   // one round of workgroups: measured crossover, DESIGN.md 3.3
+    // the fused launch always forms the stair blocks: the other preconditioner modes take the stage kernels
+    const bool fused = s->precon_mode == GATO_PRECON_STAIR &&
+                       (s->asm_mode == 2 || (s->asm_mode == 0 && (long long)s->d.K * s->d.B <= 2ll * s->num_cus));   // one round of workgroups: measured crossover, DESIGN.md 3.3
     s->last_asm_fused = fused;
     if (!fused) {
         if (mode == 0) {                 // CSR: the gather launch also inverts Q_k, R_k while they sit in LDS
@@ -778,6 +809,9 @@ static int assemble(gato_solver *s, int mode, const int *G_row, const int *G_col
         } else rc = s->ops->add_rho(s->d, G_val, rho, s->G_dense, st);
         if (rc) return rc;
         if ((rc = s->ops->form_schur(s->d, s->G_dense, C_dense, d_g, d_c, s->Sbd, s->Pbd, s->gamma, s->Ginv, mode == 0, st))) return rc;
+        // preconditioner (gato_defines.h:9-10): the Schur stage leaves the block-Jacobi one (main blocks, zeros beside them)
+        if (s->precon_mode == GATO_PRECON_BLOCK_JACOBI) return GATO_OK;                       // SS_PRECON = 0 (gato_schur.cuh:965-970)
+        if (s->precon_mode == GATO_PRECON_POINT_JACOBI) return s->ops->point_jacobi(s->d, s->Sbd, s->Pbd, st);   // both 0 (:424-428)
         return gato_form_ss(s, s->Sbd, s->Pbd, st);
     }
     if (mode == 0 && s->d.B > 1 && (s->d.nnzG <= 0 || s->d.nnzC <= 0)) {
@@ -802,10 +836,15 @@ extern "C" int gato_linsys_device(gato_solver *s, const int *d_G_row, const int 
     int rc;
     void *lam = d_lambda ? d_lambda : s->lambda;
     void *dz = d_dz ? d_dz : s->dz;
+    const bool ts = s->time_stages != 0;
+    if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[0], (hipStream_t)stream));
     if ((rc = assemble(s, 0, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, s->C_dense, d_g, d_c, rho, (hipStream_t)stream))) return rc;
+    if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[1], (hipStream_t)stream));
     s->lc = {1, s->Sbd, s->Pbd, s->gamma, s->C_dense, d_g, lam, dz, exit_tol, max_iters};
     if ((rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream))) return rc;
+    if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[2], (hipStream_t)stream));
     if ((rc = gato_compute_dz(s, s->Ginv, s->C_dense, d_g, lam, dz, stream))) return rc;
+    if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[3], (hipStream_t)stream));
     return GATO_OK;
 }
 
@@ -816,10 +855,16 @@ extern "C" int gato_linsys_device_blocks(gato_solver *s, const void *d_G_blocks,
     int rc;
     void *lam = d_lambda ? d_lambda : s->lambda;
     void *dz = d_dz ? d_dz : s->dz;
+    const bool ts = s->time_stages != 0;
+    if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[0], (hipStream_t)stream));
     if ((rc = assemble(s, 2, nullptr, nullptr, d_G_blocks, nullptr, nullptr, nullptr, d_C_blocks, d_g, d_c, rho, (hipStream_t)stream))) return rc;
+    if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[1], (hipStream_t)stream));
     s->lc = {1, s->Sbd, s->Pbd, s->gamma, d_C_blocks, d_g, lam, dz, exit_tol, max_iters};
     if ((rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream))) return rc;
-    return gato_compute_dz(s, s->Ginv, d_C_blocks, d_g, lam, dz, stream);
+    if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[2], (hipStream_t)stream));
+    if ((rc = gato_compute_dz(s, s->Ginv, d_C_blocks, d_g, lam, dz, stream))) return rc;
+    if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[3], (hipStream_t)stream));
+    return GATO_OK;
 }
 
 extern "C" int gato_shard_pcg_done(gato_solver *s, int *done, void *stream)
@@ -911,6 +956,9 @@ static int linsys_solve_host(int dtype, const int *G_row, int len_G_row, const i
     }
     const char *env = getenv("GATO_PCG_MODE");
     s->pcg_mode = env ? atoi(env) : GATO_PCG_AUTO;
+    const char *envp = getenv("GATO_PRECON");        // 0 stair (the reference's default build), 1 block-Jacobi, 2 point-Jacobi
+    s->precon_mode = envp ? atoi(envp) : GATO_PRECON_STAIR;
+    if (s->precon_mode < GATO_PRECON_STAIR || s->precon_mode > GATO_PRECON_POINT_JACOBI) s->precon_mode = GATO_PRECON_STAIR;
 
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += align_up(b ? b : 8); return o; };

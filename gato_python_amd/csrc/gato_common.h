@@ -201,6 +201,8 @@ int launch_assemble(const Dims &d, const AsmArgs &a, hipStream_t st);
 template <typename T, int S, int C>
 int launch_form_ss(const Dims &d, const T *Sbd, T *Pbd, hipStream_t st);
 template <typename T, int S, int C>
+int launch_point_jacobi(const Dims &d, const T *Sbd, T *Pbd, hipStream_t st);
+template <typename T, int S, int C>
 int launch_compute_dz(const Dims &d, const T *Ginv, const T *Cd, const T *g, const T *lambda, T *dz,
                       hipStream_t st);
 template <typename T, int S>
@@ -267,6 +269,7 @@ struct Ops {
     int (*form_schur)(const Dims &, const void *, const void *, const void *, const void *, void *, void *,
                       void *, void *, bool, hipStream_t);
     int (*form_ss)(const Dims &, const void *, void *, hipStream_t);
+    int (*point_jacobi)(const Dims &, const void *, void *, hipStream_t);
     int (*assemble)(const Dims &, const AsmArgs &, hipStream_t);
     int (*compute_dz)(const Dims &, const void *, const void *, const void *, const void *, void *,
                       hipStream_t);

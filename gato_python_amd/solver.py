@@ -172,6 +172,12 @@ class Solver:
         _lib.check(_lib.lib().gato_pcg_last_ms(self._h, ct.byref(ms)))
         return ms.value
 
+    def last_stage_ms(self):
+        """{assembly, pcg, dz} device times (ms) of the last linsys / linsys_blocks call (needs set_option("time_stages", 1))."""
+        ms = (ct.c_float * 3)()
+        _lib.check(_lib.lib().gato_last_stage_ms(self._h, ms))
+        return dict(assembly=ms[0], pcg=ms[1], dz=ms[2])
+
     def eta_history(self, n: int):
         """eta = r . Pinv r after the initial step and after each of the first n iterations (needs record_eta=1)."""
         ptr = int(_lib.lib().gato_solver_buffer(self._h, 10))

@@ -40,6 +40,12 @@ extern "C" {
 #define GATO_PCG_RESIDENT 1  /* A5: matrices register-resident for the whole solve, one persistent launch */
 #define GATO_PCG_STREAMING 2 /* A6: matrices re-read from HBM every iteration, two launches per iteration */
 
+/* Preconditioner of the whole-solve entries = the reference's compile switches BLOCK_J_PRECON / SS_PRECON
+ * (include/gato_defines.h:9-10; src/gato_schur.cuh:407-429,965-970), a runtime option here ("precon_mode"). */
+#define GATO_PRECON_STAIR 0        /* both 1 (the reference's setting): 3-band symmetric stair */
+#define GATO_PRECON_BLOCK_JACOBI 1 /* SS_PRECON 0: main blocks -theta^-1 only */
+#define GATO_PRECON_POINT_JACOBI 2 /* both 0: diag(1 / S.main_ii) */
+
 typedef struct gato_solver gato_solver;
 
 /* ---- library / device ------------------------------------------------------------------- */
@@ -81,7 +87,8 @@ void *gato_solver_buffer(gato_solver *s, int which);
  * asm_mode (whole-solve entries: 0 = auto - convert + Schur + stair as ONE fused launch when K*B <= 2 x CUs, the
  * stage kernels otherwise; 1 = stage kernels; 2 = fused; both give bit-identical buffers), pcg_semi (-1 = auto: K
  * beyond the register file runs as one persistent semi-resident launch; 0 = the streaming kernels), time_pcg (record
- * hipEvents around the PCG launch), timeout_ms (bound of every in-kernel spin, default 2000), max_workgroups (CUs a
+ * hipEvents around the PCG launch), time_stages (hipEvents around assembly / PCG / dz of the whole-solve entries),
+ * precon_mode (GATO_PRECON_*), timeout_ms (bound of every in-kernel spin, default 2000), max_workgroups (CUs a
  * persistent launch may count on; 0 = all of the device), no_single_lds / stamp_pcg / stamp_asm / ablate (diagnostics). */
 int gato_solver_set_option(gato_solver *s, const char *name, int value);
 int gato_solver_get_option(gato_solver *s, const char *name, int *value);
@@ -122,6 +129,10 @@ int gato_solver_recover(gato_solver *s, int *recovered, void *stream);
  * launch stream immediately around the kernel launch(es) (the reference times whole solves with
  * cudaEvents, gpu_library.cu:167-187).  Enabled by option "time_pcg" = 1; synchronises on the stop event. */
 int gato_pcg_last_ms(gato_solver *s, float *ms);
+/* Stage times of the most recent gato_linsys_device / _blocks call as data (the reference prints them:
+ * "Forming Schur took", gato_schur.cuh:907-913,972-982; solve time gpu_library.cu:186-198): ms[0] = scatter + Schur +
+ * preconditioner, ms[1] = PCG, ms[2] = dz.  Enabled by option "time_stages" = 1. */
+int gato_last_stage_ms(gato_solver *s, float *ms);
 /* A9  compute_dz (gato_schur.cuh:1012-1022) with d_Ginv_dense = inverses from gato_form_schur. */
 int gato_compute_dz(gato_solver *s, const void *d_Ginv_dense, const void *d_C_dense, const void *d_g,
                     const void *d_lambda, void *d_dz, void *stream);

@@ -199,6 +199,17 @@ def form_ss(S_bd, Pinv_bd, S, K):
 # --------------------------------------------------------------------------------------------
 # A7: block-tridiagonal SpMV with the K4 boundary rule   (src/gato_utils.cuh:153-185)
 # --------------------------------------------------------------------------------------------
+def point_jacobi(S_bd, S, K):
+    """The reference built with BLOCK_J_PRECON = SS_PRECON = 0 (include/gato_defines.h:9-10): Pinv[k].main =
+    diag(1 / S[k].main_ii) (src/gato_schur.cuh:424-428), zeros elsewhere."""
+    _, M, _ = unpack_bd(S_bd, S, K)
+    Z = np.zeros_like(M)
+    D = np.zeros_like(M)
+    idx = np.arange(S)
+    D[:, idx, idx] = 1.0 / M[:, idx, idx]
+    return pack_bd(Z, D, Z)
+
+
 def bt_matvec(L, M, R, x):
     """x: [K,S] -> y[K,S];  first row uses main,right; last row uses left,main."""
     y = (M @ x[:, :, None])[..., 0]
@@ -314,13 +325,18 @@ def compute_dz(Ginv_dense, C_dense, g, lam, S, C, K):
 # L3/L4: whole solve                              (gpu_library.cu:25-83)
 # --------------------------------------------------------------------------------------------
 def linsys_solve(G_row, G_col, G_val, C_row, C_col, C_val, g, c, S, C, K,
-                 exit_tol, max_iters, rho, dtype=np.float32, return_all=False):
+                 exit_tol, max_iters, rho, dtype=np.float32, return_all=False, precon_mode=0):
+    """precon_mode: 0 = symmetric stair (BLOCK_J_PRECON = SS_PRECON = 1, the reference's setting, gato_defines.h:9-10),
+    1 = block-Jacobi (SS_PRECON = 0: gato_form_ss is not launched, gato_schur.cuh:965-970), 2 = point-Jacobi (both 0)."""
     dtype = np.dtype(dtype).type
     Gd, Cd = convert(G_row, G_col, G_val, C_row, C_col, C_val, S, C, K, rho, dtype)
     g = np.asarray(g, dtype)
     c = np.asarray(c, dtype)
     S_bd, P_bd, gamma, Ginv = form_schur(Gd, Cd, g, c, S, C, K)
-    P_bd = form_ss(S_bd, P_bd, S, K)
+    if precon_mode == 0:
+        P_bd = form_ss(S_bd, P_bd, S, K)
+    elif precon_mode == 2:
+        P_bd = point_jacobi(S_bd, S, K)
     lam, iters, hist = pcg(S_bd, P_bd, gamma, S, K, exit_tol, max_iters, return_history=True)
     dz = compute_dz(Ginv, Cd, g, lam, S, C, K)
     if return_all:

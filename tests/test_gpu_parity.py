@@ -871,3 +871,61 @@ def test_handoff_timeout_is_reported_in_band_and_recovered():
     assert sol.recover() is False and sol.get_option("last_mode") == _lib.PCG_RESIDENT
     assert np.frombuffer(_read_iters(sol), np.int32)[0] == it_o and rel(host(lam), lam_o) < 1e-9
     sol.close()
+
+
+@pytest.mark.parametrize("mode", [_lib.PRECON_BLOCK_JACOBI, _lib.PRECON_POINT_JACOBI])
+@pytest.mark.parametrize("S,C,K,dt", [(14, 7, 50, np.float64), (14, 7, 600, np.float64), (2, 1, 5, np.float64), (32, 16, 9, np.float32)])
+def test_preconditioner_modes(S, C, K, dt, mode):
+    """The reference's compile switches BLOCK_J_PRECON / SS_PRECON (gato_defines.h:9-10) as the runtime option precon_mode:
+    Pinv and the whole solve against the oracle run in the same mode (same iteration count in fp64)."""
+    s = system(S, C, K, seed=8) if (S, C, K) != (2, 1, 5) else synth.pendulum_system()
+    f64 = dt == np.float64
+    sol = make_solver(S, C, K, dt)
+    sol.set_option("precon_mode", mode)
+    sol.set_option("time_stages", 1)
+    dev = sol.upload_system(s)
+    lam, dz = sol.new(S * K), sol.new(sol.N)
+    # fixed iteration count: the same iterates as the oracle in that mode
+    n_it = 4 if K == 5 else 15
+    out = o.linsys_solve(*s.csr_args(), S, C, K, 0.0, n_it, s.rho, dtype=dt, return_all=True, precon_mode=mode)
+    sol.linsys(*dev, 0.0, n_it, s.rho, lam, dz)
+    sol.check_status()
+    assert sol.get_option("last_asm_fused") == 0
+    assert rel(sol.read_buffer("Pinv"), out["Pinv"]) < (1e-11 if f64 else 3e-4)
+    assert int(np.frombuffer(_read_iters(sol), np.int32)[0]) == n_it
+    if f64:
+        assert rel(host(lam), out["lam"]) < 1e-9 and rel(host(dz), out["dz"]) < 1e-9
+    elif mode == _lib.PRECON_BLOCK_JACOBI:   # fp32: judged against the fp64 iterates, beside the fp32 oracle's error
+        t = o.linsys_solve(*s.csr_args(), S, C, K, 0.0, n_it, s.rho, dtype=np.float64, return_all=True, precon_mode=mode)
+        check_f32(f"precon mode {mode} {S}/{C}/{K} lambda after {n_it}", host(lam), out["lam"], t["lam"], floor=1e-4)
+    # (fp32 point-Jacobi: 15 iterations of barely preconditioned CG in single precision differ by percents between any two
+    #  summation orders - the oracle's own error against fp64 is 8e-3 there; only Pinv and the converged solve are compared)
+    # to tolerance: a weaker preconditioner needs more iterations (their number depends on rounding when convergence is
+    # slow: within 5 % of the oracle's) and reaches the same solution
+    tol, mi = (1e-9, 3000) if f64 else (1e-4, 400)
+    out = o.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt, return_all=True, precon_mode=mode)
+    sol.linsys(*dev, tol, mi, s.rho, lam, dz)
+    sol.check_status()
+    it = int(np.frombuffer(_read_iters(sol), np.int32)[0])
+    assert abs(it - out["iters"]) <= max(2, out["iters"] // 20), (it, out["iters"])
+    assert rel(host(lam), out["lam"]) < (1e-5 if f64 else 2e-2)
+    ms = sol.last_stage_ms()
+    assert ms["assembly"] > 0 and ms["pcg"] > 0 and ms["dz"] > 0
+    sol.close()
+
+
+def test_stage_times_as_data():
+    """gato_last_stage_ms (the reference prints its Schur and solve times, gato_schur.cuh:907-913,972-982)."""
+    S, C, K = 14, 7, 50
+    s = system(S, C, K, seed=0)
+    sol = make_solver(S, C, K, np.float64)
+    dev = sol.upload_system(s)
+    lam, dz = sol.new(S * K), sol.new(sol.N)
+    with pytest.raises(_lib.GatoError):
+        sol.last_stage_ms()
+    sol.set_option("time_stages", 1)
+    for _ in range(3):
+        sol.linsys(*dev, 0.0, 100, s.rho, lam, dz)
+    ms = sol.last_stage_ms()
+    assert 0.001 < ms["assembly"] < 1.0 and 0.05 < ms["pcg"] < 5.0 and 0.0005 < ms["dz"] < 1.0, ms
+    sol.close()

@@ -124,3 +124,20 @@ def test_generator_structure():
     assert np.allclose(Cm[:14, :14].toarray(), np.eye(14))
     assert np.allclose(Cm[14:28, 21:35].toarray(), np.eye(14))
     assert np.all(s.c[:14] == 0)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_other_preconditioner_modes_still_solve_the_kkt_system(mode):
+    """BLOCK_J_PRECON / SS_PRECON (gato_defines.h:9-10) only change the preconditioner: PCG run to a tight tolerance reaches
+    the dense KKT solution with every one of them, in more iterations than the stair preconditioner needs."""
+    S, C, K = 14, 7, 12
+    s = synth.make_system(S, C, K, seed=9)
+    dz_ref, lam_ref = synth.dense_kkt_solve(s)
+    out0 = o.linsys_solve(*s.csr_args(), S, C, K, 1e-20, 2000, s.rho, dtype=np.float64, return_all=True)
+    out = o.linsys_solve(*s.csr_args(), S, C, K, 1e-20, 2000, s.rho, dtype=np.float64, return_all=True, precon_mode=mode)
+    assert rel(out["lam"], lam_ref) < 1e-7 and rel(out["dz"], dz_ref) < 1e-7
+    assert out["iters"] >= out0["iters"]
+    L, M, R = o.unpack_bd(out["Pinv"], S, K)
+    assert not L.any() and not R.any()
+    if mode == 2:
+        assert np.count_nonzero(M) == S * K
