@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void invert_G_kernel(const T *__restrict__ Gd,
     Gd += blockIdx.y * bs.g; Ginv += blockIdx.y * bs.g;
     const int lane = threadIdx.x & 63;
     const int nmat = 2 * K - 1;                                   // Q_0, R_0, Q_1, ..., Q_{K-1}
-    for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < nmat; m += gridDim.x * 4) {
+    const int m_hi = 2 * bs.k_hi - 1 < nmat ? 2 * bs.k_hi - 1 + (bs.k_hi < K ? 1 : 0) : nmat;   // Q and R of the knots [k_lo, k_hi)
+    for (int m = 2 * bs.k_lo + blockIdx.x * 4 + (threadIdx.x >> 6); m < m_hi; m += gridDim.x * 4) {
         const int k = m >> 1;
         const size_t off = (size_t)k * (SS + CC);
         if ((m & 1) == 0) invert_to<T, S>(Gd + off, Ginv + off, lane, (T)1);
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, c
     __shared__ T sA[SS], sB[SC], sQim[SS], sQik[SS], sRim[CC], sPhi[SS], sBR[SC], sTh[SS];
     __shared__ T sq[2 * S + C], sv[3 * S];
     const int lane = threadIdx.x;
-    for (int k = blockIdx.x; k < K; k += gridDim.x) {
+    for (int k = bs.k_lo + blockIdx.x; k < bs.k_hi; k += gridDim.x) {
         T *Sk = Sbd + (size_t)k * 3 * SS;
         T *Pk = Pbd + (size_t)k * 3 * SS;
         wave_sync();
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(WAVE) void ss_kernel(const T *__restrict__ Sbd, T *
     Sbd += blockIdx.y * bs.bd; Pbd += blockIdx.y * bs.bd;
     __shared__ T sPm[SS], sX[SS], sPn[SS], sT[SS];
     const int lane = threadIdx.x;
-    for (int k = blockIdx.x; k < K; k += gridDim.x) {
+    for (int k = bs.k_lo + blockIdx.x; k < bs.k_hi; k += gridDim.x) {
         T *Pk = Pbd + (size_t)k * 3 * SS;
         wave_sync();
         copy_in(sPm, Pk + SS, SS, lane);
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(NT) void gather_kernel(const int *__restrict__ G_ro
     G_val += blockIdx.y * bs.nnzG; C_val += blockIdx.y * bs.nnzC;            // batch: shared structure, own values
     Gd += blockIdx.y * bs.g; Cd += blockIdx.y * bs.c;
     if (Ginv) Ginv += blockIdx.y * bs.g;
-    for (int k = blockIdx.x; k < K; k += gridDim.x) {
+    for (int k = bs.k_lo + blockIdx.x; k < bs.k_hi; k += gridDim.x) {
         const bool last = k == K - 1;
         const int r0 = k * n, nrG = last ? S : n;
         const int c0 = (k + 1) * S, nrC = last ? 0 : S;
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(WAVE) void dz_kernel(const T *__restrict__ Ginv, co
     dz += blockIdx.y * bs.n;
     __shared__ T sQi[SS], sA[SS], sRi[CC > 0 ? CC : 1], sB[SC > 0 ? SC : 1], sl[2 * S], st[S + C], sg[S + C];
     const int lane = threadIdx.x;
-    for (int k = blockIdx.x; k < K; k += gridDim.x) {
+    for (int k = bs.k_lo + blockIdx.x; k < bs.k_hi; k += gridDim.x) {
         const bool last = k == K - 1;
         wave_sync();
         copy_in(sQi, Ginv + (size_t)k * (SS + CC), SS, lane);
@@ -726,7 +727,7 @@ int launch_convert(const Dims &d, const int *G_row, const int *G_col, const T *G
                    const int *C_col, const T *C_val, T rho, T *Gd, T *Cd, T *Ginv, hipStream_t st)
 {
     constexpr int NT = 128;
-    hipLaunchKernelGGL((gather_kernel<T, S, C, NT>), dim3(d.K < (1 << 20) ? d.K : (1 << 20), d.B), dim3(NT), 0, st, G_row, G_col,
+    hipLaunchKernelGGL((gather_kernel<T, S, C, NT>), dim3(d.hi() - d.lo() < (1 << 20) ? d.hi() - d.lo() : (1 << 20), d.B), dim3(NT), 0, st, G_row, G_col,
                        G_val, C_row, C_col, C_val, d.K, rho, Gd, Cd, Ginv, batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
     return GATO_OK;
@@ -749,12 +750,12 @@ int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const
                       T *gamma, T *Ginv, bool have_inverses, hipStream_t st)
 {
     if (!have_inverses) {
-        const int nblk = (2 * d.K - 1 + 3) / 4;
+        const int nblk = (2 * (d.hi() - d.lo()) + 3) / 4;
         hipLaunchKernelGGL((invert_G_kernel<T, S, C>), dim3(nblk < 8192 ? nblk : 8192, d.B), dim3(256), 0, st, Gd, Ginv, d.K,
                            batch_stride(d));
         GATO_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL((schur_kernel<T, S, C>), dim3(knot_grid(d.K), d.B), dim3(WAVE), 0, st, Gd, Ginv, Cd, g, c, d.K,
+    hipLaunchKernelGGL((schur_kernel<T, S, C>), dim3(knot_grid(d.hi() - d.lo()), d.B), dim3(WAVE), 0, st, Gd, Ginv, Cd, g, c, d.K,
                        Sbd, Pbd, gamma, batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
     return GATO_OK;
@@ -784,7 +785,7 @@ int launch_assemble(const Dims &d, const AsmArgs &a, hipStream_t st)
 template <typename T, int S, int C>
 int launch_form_ss(const Dims &d, const T *Sbd, T *Pbd, hipStream_t st)
 {
-    hipLaunchKernelGGL((ss_kernel<T, S>), dim3(knot_grid(d.K), d.B), dim3(WAVE), 0, st, Sbd, Pbd, d.K, batch_stride(d));
+    hipLaunchKernelGGL((ss_kernel<T, S>), dim3(knot_grid(d.hi() - d.lo()), d.B), dim3(WAVE), 0, st, Sbd, Pbd, d.K, batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
     return GATO_OK;
 }
@@ -803,7 +804,7 @@ template <typename T, int S, int C>
 int launch_compute_dz(const Dims &d, const T *Ginv, const T *Cd, const T *g, const T *lambda, T *dz,
                       hipStream_t st)
 {
-    hipLaunchKernelGGL((dz_kernel<T, S, C>), dim3(knot_grid(d.K), d.B), dim3(WAVE), 0, st, Ginv, Cd, g, lambda, d.K, dz,
+    hipLaunchKernelGGL((dz_kernel<T, S, C>), dim3(knot_grid(d.hi() - d.lo()), d.B), dim3(WAVE), 0, st, Ginv, Cd, g, lambda, d.K, dz,
                        batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
     return GATO_OK;

@@ -434,6 +434,10 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "true_warm_start")) s->true_warm_start = value;
     else if (!strcmp(name, "timeout_ms")) s->timeout_ms = value > 0 ? value : 2000;
     else if (!strcmp(name, "max_workgroups")) s->max_workgroups = value;
+    else if (!strcmp(name, "knot_lo") || !strcmp(name, "knot_hi")) {          // stage-level entries: knots [knot_lo, knot_hi)
+        if (value < 0 || value > s->d.K) { set_error("%s = %d is outside [0, %d]", name, value, s->d.K); return GATO_EINVAL; }
+        (name[5] == 'l' ? s->d.k_lo : s->d.k_hi) = value;
+    }
     else if (!strcmp(name, "precon_mode")) {
         if (value < GATO_PRECON_STAIR || value > GATO_PRECON_POINT_JACOBI) { set_error("precon_mode must be 0, 1 or 2"); return GATO_EINVAL; }
         s->precon_mode = value;
@@ -773,6 +777,7 @@ extern "C" int gato_solver_recover(gato_solver *s, int *recovered, void *stream)
     if (rc == GATO_OK) return GATO_OK;
     if (rc != GATO_ETIMEOUT || !s->lc.valid) return rc;
     const int saved = s->pcg_mode;
+    s->d.k_lo = s->d.k_hi = 0;
     s->pcg_mode = GATO_PCG_STREAMING;
     int rc2 = gato_pcg(s, s->lc.S, s->lc.P, s->lc.gamma, s->lc.lam, s->lc.exit_tol, s->lc.max_iters, s->iters, stream);
     s->pcg_mode = saved;
@@ -798,6 +803,7 @@ static int assemble(gato_solver *s, int mode, const int *G_row, const int *G_col
                     hipStream_t st)
 {
     int rc;
+    s->d.k_lo = s->d.k_hi = 0;              // whole solves work on every knot: the knot-range option is for the stage entries
     // the fused launch always forms the stair blocks: the other preconditioner modes take the stage kernels
     const bool fused = s->precon_mode == GATO_PRECON_STAIR &&
                        (s->asm_mode == 2 || (s->asm_mode == 0 && (long long)s->d.K * s->d.B <= 2ll * s->num_cus));   // one round of workgroups: measured crossover, DESIGN.md 3.3

@@ -90,6 +90,11 @@ struct Dims {
     int S, C, K;
     int B = 1;
     int nnzG = 0, nnzC = 0;
+    // stage-level entries only: knots [k_lo, k_hi) to work on (k_hi = 0: all).  A rank of a multi-GPU solve assembles
+    // just the block rows its PCG shard reads (gato_python_amd/dist.py: assemble_shard)
+    int k_lo = 0, k_hi = 0;
+    __host__ __device__ int lo() const { return k_lo; }
+    __host__ __device__ int hi() const { return k_hi > 0 ? k_hi : K; }
     __host__ __device__ int n() const { return S + C; }
     __host__ __device__ size_t N() const { return (size_t)(S + C) * K - C; }
     __host__ __device__ size_t g_dense() const { return (size_t)(S * S + C * C) * K - C * C; }
@@ -100,10 +105,11 @@ struct Dims {
 
 struct BatchStride {
     size_t g, c, bd, sk, n, nnzG, nnzC;     // elements per system: G_dense, C_dense, S/Pinv, gamma/lambda, g/dz, CSR values
+    int k_lo, k_hi;                         // knots the launch works on
 };
 inline BatchStride batch_stride(const Dims &d)
 {
-    return BatchStride{d.g_dense(), d.c_dense(), d.bd(), d.sk(), d.N(), (size_t)d.nnzG, (size_t)d.nnzC};
+    return BatchStride{d.g_dense(), d.c_dense(), d.bd(), d.sk(), d.N(), (size_t)d.nnzG, (size_t)d.nnzC, d.lo(), d.hi()};
 }
 
 // ---- persistent (resident) PCG launch description ------------------------------------------

@@ -322,6 +322,51 @@ def run_cluster_lockstep(solvers, Sb, Pb, gamma, exit_tol, max_iters):
     return lam, out
 
 
+def assemble_shard(sol, d, rho, k0, k1, out=None):
+    """Stage kernels restricted to what the PCG shard [k0, k1) of this rank reads (full-size buffers, only these rows
+    are written): S / Pinv rows k0..k1-1 complete (S[k].right comes from the Schur step of knot k+1, the stair blocks
+    need theta^-1 of both neighbours) and gamma on k0-1..k1 (ghosts of the initial residual).  Hence
+    gather + inversions on [k0-2, k1+1), Schur on [k0-1, k1+1), stair on [k0, k1).  Returns (Gd, Cd, Sb, Pb, gamma, Ginv)."""
+    K = sol.K
+    clip = lambda a: max(0, min(K, a))
+
+    def rng(lo, hi):
+        sol.set_option("knot_lo", clip(lo))
+        sol.set_option("knot_hi", clip(hi))
+    if out is None:
+        import torch
+        z = lambda n: torch.zeros(int(max(n, 1)), dtype=sol.dtype, device=f"cuda:{sol.device}")
+        out = dict(Gd=z(sol.sizes["G_dense"]), Cd=z(sol.sizes["C_dense"]), Sb=z(sol.sizes["bd"]), Pb=z(sol.sizes["bd"]),
+                   gam=z(sol.sizes["sk"]), Gi=z(sol.sizes["G_dense"]))
+    from . import _lib
+    from .solver import _ptr
+    L = _lib.lib()
+    rng(k0 - 2, k1 + 1)
+    _lib.check(L.gato_convert(sol._h, _ptr(d[0]), _ptr(d[1]), _ptr(d[2]), _ptr(d[3]), _ptr(d[4]), _ptr(d[5]), float(rho),
+                              _ptr(out["Gd"]), _ptr(out["Cd"]), sol._stream()))
+    # gato_form_schur inverts the Q_k, R_k of its knot range first: the range must cover knot k-1 of every Schur step, so
+    # the inversions run on [k0-2, k1+1) and the Schur steps on [k0-1, k1+1) (their extra first knot only rewrites the
+    # rows k0-2 of S / Pinv, which nobody reads)
+    _lib.check(L.gato_form_schur(sol._h, _ptr(out["Gd"]), _ptr(out["Cd"]), _ptr(d[6]), _ptr(d[7]), _ptr(out["Sb"]), _ptr(out["Pb"]),
+                                 _ptr(out["gam"]), _ptr(out["Gi"]), sol._stream()))
+    rng(k0, k1)
+    _lib.check(L.gato_form_ss(sol._h, _ptr(out["Sb"]), _ptr(out["Pb"]), sol._stream()))
+    rng(0, 0)
+    return out
+
+
+def dz_shard(sol, d, bufs, lam, dz, k0, k1):
+    """dz rows of the knots [k0, k1) into the full-size buffer dz (lam: the assembled lambda - knot k needs lambda_{k+1})."""
+    from . import _lib
+    from .solver import _ptr
+    sol.set_option("knot_lo", k0)
+    sol.set_option("knot_hi", k1)
+    _lib.check(_lib.lib().gato_compute_dz(sol._h, _ptr(bufs["Gi"]), _ptr(bufs["Cd"]), _ptr(d[6]), _ptr(lam), _ptr(dz), sol._stream()))
+    sol.set_option("knot_lo", 0)
+    sol.set_option("knot_hi", 0)
+    return dz
+
+
 def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None, state=None):
     """Whole solve with the PCG sharded over the ranks of `group` through the in-kernel xGMI hand-off.  Assembly is
     replicated (one-off O(K), needs no exchange), each rank's launch solves its knot range, lambda is assembled by one
@@ -330,18 +375,21 @@ def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=Non
     import torch
     import torch.distributed as dist
     from .solver import Solver
+    """Assembly is SHARDED too (assemble_shard: every rank forms the block rows its PCG shard reads, plus the few halo
+    knots they depend on), so the whole step scales, not only the iteration loop."""
     rank, nranks = dist.get_rank(group), dist.get_world_size(group)
     if state is None:
         dev = torch.cuda.current_device() if device is None else device
         sol = Solver(sysm.S, sysm.C, sysm.K, dtype, dev)
         state = dict(sol=sol, d=sol.upload_system(sysm), cl=ClusterPCG(sol, rank, nranks, group))
     sol, d, cl = state["sol"], state["d"], state["cl"]
-    Gd, Cd = sol.convert(*d[:6], sysm.rho)
-    Sb, Pb, gam, Gi = sol.form_schur(Gd, Cd, d[6], d[7])
-    sol.form_ss(Sb, Pb)
-    lam = torch.zeros(sol.S * sol.K, dtype=sol.dtype, device=Sb.device)
-    iters = torch.zeros(1, dtype=torch.int32, device=Sb.device)
-    cl.pcg(Sb, Pb, gam, exit_tol, max_iters, lam, iters)
-    allreduce_sum_(lam, group)
-    dz = sol.compute_dz(Gi, Cd, d[6], lam)
+    b = state["bufs"] = assemble_shard(sol, d, sysm.rho, cl.k0, cl.k1, state.get("bufs"))
+    dev = b["Sb"].device
+    lam = torch.zeros(sol.S * sol.K, dtype=sol.dtype, device=dev)
+    dz = torch.zeros(sol.N, dtype=sol.dtype, device=dev)
+    iters = torch.zeros(1, dtype=torch.int32, device=dev)
+    cl.pcg(b["Sb"], b["Pb"], b["gam"], exit_tol, max_iters, lam, iters)
+    allreduce_sum_(lam, group)                      # disjoint slices -> the whole lambda on every rank (once per solve)
+    dz_shard(sol, d, b, lam, dz, cl.k0, cl.k1)
+    allreduce_sum_(dz, group)
     return lam, dz, iters, state

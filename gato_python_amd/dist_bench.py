@@ -5,7 +5,7 @@ every rank, each rank its own system, no data-path collective: weak scaling, val
 directly comparable with the N = 1 line ("replicas": that shape is one workgroup on one CU, it does not shard).  The
 same JSON line carries, as "sharded", the knot-sharded solves that DO exchange data - configs[3] (IIWA 14/7, K = 4096)
 and K = 262144 (the size where splitting can pay) split over the ranks, strong scaling: a step = replicated assembly +
-sharded PCG of exactly 100 iterations + dz - each with its us per iteration next to the same system on ONE GPU.
+sharded PCG of exactly 100 iterations + dz (xgmi transport: assembly and dz sharded too) - each with its us per iteration next to the same system on ONE GPU.
 Transport of the sharded PCG: "xgmi" = ONE persistent launch per rank with the dot + halo exchange inside the kernel
 (peer stores into IPC-mapped mirrors, gato_cluster_*); if the mirrors cannot be mapped or the first solve times out,
 "rccl" = two launches + two RCCL all-gathers per iteration (gato_shard_pcg_*).  The line says which one ran.
@@ -120,7 +120,8 @@ def replicas_leg(args, torch, dist, rank, local, world):
 
 def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
     from . import synth
-    from .dist import (ClusterPCG, ClusterUnavailable, HipShardBackend, ShardedPCG, _all_ranks_ok, allreduce_sum_)
+    from .dist import (ClusterPCG, ClusterUnavailable, HipShardBackend, ShardedPCG, _all_ranks_ok, allreduce_sum_, assemble_shard,
+                       dz_shard)
     from .solver import Solver
     S, C, K, dt = WORKLOADS[name]
     sysm = synth.make_system(S, C, K, seed=0)
@@ -144,13 +145,20 @@ def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
         sol.form_ss(Sb, Pb)
         return Cd, Sb, Pb, gam, Gi
 
+    xb = {}
+
     def step_xgmi():
-        Cd, Sb, Pb, gam, Gi = assemble()
+        # every rank assembles only the block rows its shard reads; lambda and dz are assembled by one sum-all-reduce each
+        # per solve (disjoint slices), outside the iteration loop
+        b = xb["b"] = assemble_shard(sol, d, sysm.rho, cl.k0, cl.k1, xb.get("b"))
         lam = torch.zeros(S * K, dtype=sol.dtype, device=dev)
+        dz = torch.zeros(sol.N, dtype=sol.dtype, device=dev)
         iters = torch.zeros(1, dtype=torch.int32, device=dev)
-        cl.pcg(Sb, Pb, gam, 0.0, MAX_ITERS, lam, iters)
-        allreduce_sum_(lam)                               # once per solve, outside the iteration loop
-        return lam, sol.compute_dz(Gi, Cd, d[6], lam), iters
+        cl.pcg(b["Sb"], b["Pb"], b["gam"], 0.0, MAX_ITERS, lam, iters)
+        allreduce_sum_(lam)
+        dz_shard(sol, d, b, lam, dz, cl.k0, cl.k1)
+        allreduce_sum_(dz)
+        return lam, dz, iters
 
     def step_rccl():
         Cd, Sb, Pb, gam, Gi = assemble()

@@ -88,7 +88,9 @@ void *gato_solver_buffer(gato_solver *s, int which);
  * stage kernels otherwise; 1 = stage kernels; 2 = fused; both give bit-identical buffers), pcg_semi (-1 = auto: K
  * beyond the register file runs as one persistent semi-resident launch; 0 = the streaming kernels), time_pcg (record
  * hipEvents around the PCG launch), time_stages (hipEvents around assembly / PCG / dz of the whole-solve entries),
- * precon_mode (GATO_PRECON_*), timeout_ms (bound of every in-kernel spin, default 2000), max_workgroups (CUs a
+ * precon_mode (GATO_PRECON_*), knot_lo / knot_hi (the stage-level entries gato_convert / gato_form_schur / gato_form_ss /
+ * gato_compute_dz then work on the knots [knot_lo, knot_hi) only - a rank of a multi-GPU solve assembles just what its
+ * PCG shard reads; reset by every whole-solve call), timeout_ms (bound of every in-kernel spin, default 2000), max_workgroups (CUs a
  * persistent launch may count on; 0 = all of the device), no_single_lds / stamp_pcg / stamp_asm / ablate (diagnostics). */
 int gato_solver_set_option(gato_solver *s, const char *name, int value);
 int gato_solver_get_option(gato_solver *s, const char *name, int *value);

@@ -151,3 +151,23 @@ if rows:
         for k, v in sorted(rows.items()):
             f.write(f'"{k[0]}",{k[1]},{len(next(iter(v.values())))},' + ",".join(f"{sum(v[n]) / len(v[n]):.0f}" if v.get(n) else "" for n in names) + "\n")
 print("wrote", sorted(os.listdir(out)))
+
+# cache counters of the semi-resident K = 131072 launch: one pass per counter (tools/profile.sh)
+cache = {}
+for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_cache_*"))):
+    if not os.path.isdir(d):
+        continue
+    g = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    if not g:
+        continue
+    for r in csv.DictReader(open(max(g, key=os.path.getmtime))):
+        if "pcg_resident_kernel" in r["Kernel_Name"]:
+            cache.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+if cache:
+    with open(os.path.join(out, f"{tag}_cache_counters.csv"), "w") as f:
+        f.write("kernel,workload,counter,launches,avg_per_launch,note\n")
+        for k, v in sorted(cache.items()):
+            v = v[1:] if len(v) > 1 else v            # the first launch also reads the matrices into the register-resident rows
+            f.write(f'"pcg_resident_kernel (semi-resident, 256 x 512)","iiwa 14/7/131072 f32, 10 iterations per launch",{k},{len(v)},{sum(v) / len(v):.0f},'
+                    f'"one rocprofv3 --pmc pass per counter"\n')
+    print("wrote cache counters:", sorted(cache))
