@@ -29,7 +29,7 @@ trace = one(f"prof_{tag}_stats/*/*_kernel_trace.csv")
 launch = defaultdict(list)
 if trace:
     for r in csv.DictReader(open(trace)):
-        if "pcg_" in r["Kernel_Name"] or "stream_step" in r["Kernel_Name"]:
+        if ("pcg_" in r["Kernel_Name"] or "stream_step" in r["Kernel_Name"]) and not re.search(r"pcg_resident_kernel<\w+, \d+, \d+, \d+, true,", r["Kernel_Name"]):
             key = (short(r["Kernel_Name"]),
                    int(r["Grid_Size_X"] if "Grid_Size_X" in r else r["Grid_Size"]),
                    int(r["Workgroup_Size_X"] if "Workgroup_Size_X" in r else r["Workgroup_Size"]))
@@ -38,11 +38,14 @@ if trace:
         f.write("kernel,grid_threads,workgroup_threads,launches,avg_ns,min_ns,max_ns\n")
         for k, v in sorted(launch.items()):
             groups = [v]
-            if max(v) > 1.6 * min(v) and ", 16, false>" in k[0]:      # two bench workloads on one (kernel, grid): split by duration
+            if max(v) > 1.6 * min(v) and ", 16, false" in k[0]:      # two bench workloads on one (kernel, grid): split by duration
                 cut = (max(v) + min(v)) / 2
                 groups = [[x for x in v if x < cut], [x for x in v if x >= cut]]
             for g in groups:
                 f.write(f'"{k[0]}",{k[1]},{k[2]},{len(g)},{sum(g) / len(g):.0f},{min(g)},{max(g)}\n')
+
+
+DIAG = re.compile(r"pcg_resident_kernel<\w+, \d+, \d+, \d+, true,")      # the diagnostic (STAMP) build: bench.py's latency-floor launches
 
 
 def counter(kind):
@@ -50,6 +53,8 @@ def counter(kind):
     acc = defaultdict(list)
     if p:
         for r in csv.DictReader(open(p)):
+            if DIAG.search(r["Kernel_Name"]):
+                continue
             if "pcg_" in r["Kernel_Name"] or "stream_step" in r["Kernel_Name"]:
                 key = (short(r["Kernel_Name"]), int(r["Grid_Size"]), int(r["Workgroup_Size"]))
                 acc[key].append(float(r["Counter_Value"]))
@@ -82,7 +87,7 @@ for name, (prefix, K) in WL.items():
     for key in fetch:
         if key[0].startswith(prefix) and geom.get(name) in (key[1], key[1] // 8 if key[1] % 8 == 0 else -1):   # xcd_pack launches an 8x grid
             fv, wv = fetch[key], write.get(key, [])
-            if ", 16, false>" in key[0] and ("iiwa_14_7_k16384_f32" in geom and "iiwa_14_7_k131072_f32" in geom):
+            if ", 16, false" in key[0] and ("iiwa_14_7_k16384_f32" in geom and "iiwa_14_7_k131072_f32" in geom):
                 big = name == "iiwa_14_7_k131072_f32"
                 fv = [v for v in fv if (v >= max(fetch[key]) / 2) == big]
                 wv = [v for v in wv if (v >= max(write[key]) / 2) == big] if wv else wv
