@@ -187,8 +187,11 @@ __global__ __launch_bounds__(256) void invert_G_kernel(const T *__restrict__ Gd,
 }
 
 // ---- A2b: Schur blocks, block-Jacobi main blocks, gamma (gato_schur.cuh:13-460) -----------------
+// waves per SIMD the register allocation must leave room for (one-wave workgroups: latency-bound launches want many knots in flight)
+template <typename T, int S> struct AsmWaves { static constexpr int v = S <= 16 ? (sizeof(T) == 8 ? 4 : 5) : 1; };
+
 template <typename T, int S, int C>
-__global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, const T *__restrict__ Ginv,
+__global__ __launch_bounds__(WAVE, (AsmWaves<T, S>::v)) void schur_kernel(const T *__restrict__ Gd, const T *__restrict__ Ginv,
                                                      const T *__restrict__ Cd, const T *__restrict__ g,
                                                      const T *__restrict__ c, int K, T *__restrict__ Sbd,
                                                      T *__restrict__ Pbd, T *__restrict__ gamma, BatchStride bs)
@@ -196,17 +199,18 @@ __global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, c
     constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C;
     Gd += blockIdx.y * bs.g; Ginv += blockIdx.y * bs.g; Cd += blockIdx.y * bs.c; g += blockIdx.y * bs.n;
     c += blockIdx.y * bs.sk; Sbd += blockIdx.y * bs.bd; Pbd += blockIdx.y * bs.bd; gamma += blockIdx.y * bs.sk;
-    __shared__ T sA[SS], sB[SC], sQim[SS], sQik[SS], sRim[CC], sPhi[SS], sBR[SC], sTh[SS];
-    __shared__ T sq[2 * S + C], sv[3 * S];
+    // Only what one product hands to the next goes through LDS (phi, BR, theta); the operands that come from memory
+    // (A, B, the inverses, q) are read from there by the lanes that feed them to the matrix cores / the FMAs: 4.5 KB of
+    // LDS per wave instead of 10.4 KB, i.e. twice the knots in flight per CU - these launches are latency bound.
+    __shared__ T sPhi[SS], sBR[SC], sTh[SS];
+    __shared__ T sv[3 * S];
     const int lane = threadIdx.x;
     for (int k = bs.k_lo + blockIdx.x; k < bs.k_hi; k += gridDim.x) {
         T *Sk = Sbd + (size_t)k * 3 * SS;
         T *Pk = Pbd + (size_t)k * 3 * SS;
         wave_sync();
         if (k == 0) {                                                        // :26-147
-            copy_in(sQik, Ginv, SS, lane);
-            copy_in(sq, g, S, lane);
-            wave_sync();
+            const T *sQik = Ginv, *sq = g;
             mv<T, S, S>(sv, sQik, sq, lane);
             for (int i = lane; i < SS; i += WAVE) {
                 Sk[i] = (T)0;                                                // S[0].left: unused (:157-165)
@@ -222,14 +226,9 @@ __global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, c
         }
         const size_t gm = (size_t)(k - 1) * (SS + CC), gk = (size_t)k * (SS + CC);
         const size_t cm = (size_t)(k - 1) * (SS + SC);
-        copy_in(sA, Cd + cm, SS, lane);                                      // :189-196
-        copy_in(sB, Cd + cm + SS, SC, lane);
-        copy_in(sQim, Ginv + gm, SS, lane);
-        copy_in(sRim, Ginv + gm + SS, CC, lane);
-        copy_in(sQik, Ginv + gk, SS, lane);
-        copy_in(sq, g + (size_t)(k - 1) * n, n, lane);                       // q_{k-1}, r_{k-1}
-        copy_in(sq + n, g + (size_t)k * n, S, lane);                         // q_k
-        wave_sync();
+        const T *sA = Cd + cm, *sB = Cd + cm + SS;                           // :189-196
+        const T *sQim = Ginv + gm, *sRim = Ginv + gm + SS, *sQik = Ginv + gk;
+        const T *sq = g + (size_t)(k - 1) * n;                               // q_{k-1}, r_{k-1}, and q_k n further (u_{k-1} is C long)
         // phi = A Q_{k-1}^-1 (:277-285), BR = B R_{k-1}^-1 (:293-301): matrix cores, results to LDS and S[k].left
         mfma_for_tiles<T, S, S>(lane,
             [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sA, sQim, mt, nt, lane, acc); },
@@ -262,10 +261,14 @@ __global__ __launch_bounds__(WAVE) void schur_kernel(const T *__restrict__ Gd, c
             gt += sv[2 * S + i] + sv[S + i];                                 // :336-338
             gamma[(size_t)k * S + i] = -gt;                                  // :435-438
         }
-        for (int i = lane; i < SS; i += WAVE) {
-            Pk[i] = (T)0;                                                    // stair blocks come from form_ss
-            Pk[2 * SS + i] = (T)0;
-            if (k == K - 1) Sk[2 * SS + i] = (T)0;                           // last right: unused (:166-174)
+        // block-Jacobi off-diagonals are zero; when the stair launch follows (bs.stair_follows) it writes Pinv[k].left and,
+        // for k < K-1, Pinv[k].right itself, so only the last knot's right block is zeroed here
+        if (!bs.stair_follows || k == K - 1) {
+            for (int i = lane; i < SS; i += WAVE) {
+                if (!bs.stair_follows) Pk[i] = (T)0;
+                Pk[2 * SS + i] = (T)0;
+                if (k == K - 1) Sk[2 * SS + i] = (T)0;                       // last right: unused (:166-174)
+            }
         }
         invert_to<T, S>(sTh, Pk + SS, lane, (T)-1);                          // Pinv[k].main = -theta^-1  :407-422
     }
@@ -293,35 +296,38 @@ __global__ __launch_bounds__(WAVE) void ss_kernel(const T *__restrict__ Sbd, T *
 {
     constexpr int SS = S * S;
     Sbd += blockIdx.y * bs.bd; Pbd += blockIdx.y * bs.bd;
-    __shared__ T sPm[SS], sX[SS], sPn[SS], sT[SS];
+    // operands straight from memory, only the intermediate products go through LDS (see schur_kernel); the left and the
+    // right pair are independent chains: both first products, then both second products
+    __shared__ T sT[2][SS];
     const int lane = threadIdx.x;
     for (int k = bs.k_lo + blockIdx.x; k < bs.k_hi; k += gridDim.x) {
         T *Pk = Pbd + (size_t)k * 3 * SS;
+        const T *sPm = Pk + SS;
+        const bool has_l = k > 0, has_r = k < K - 1;                         // right pair for k < K-1 only (D1)
         wave_sync();
-        copy_in(sPm, Pk + SS, SS, lane);
-        if (k > 0) {                                                         // :578-611
-            copy_in(sX, Sbd + (size_t)k * 3 * SS, SS, lane);                 // S[k].left
-            copy_in(sPn, Pbd + (size_t)(k - 1) * 3 * SS + SS, SS, lane);     // Pinv[k-1].main
-            wave_sync();
+        if (has_l) {                                                         // :578-611
+            const T *sX = Sbd + (size_t)k * 3 * SS;                          // S[k].left
             mfma_for_tiles<T, S, S>(lane,
                 [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sPm, sX, mt, nt, lane, acc); },
-                [&](int r, int cc, T v) { sT[cc * S + r] = v; });
-            wave_sync();
-            mfma_for_tiles<T, S, S>(lane,
-                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sT, sPn, mt, nt, lane, acc); },
-                [&](int r, int cc, T v) { Pk[cc * S + r] = -v; });
+                [&](int r, int cc, T v) { sT[0][cc * S + r] = v; });
         }
-        if (k < K - 1) {                                                     // :614-648 (k < K-1 only: D1)
-            wave_sync();
-            copy_in(sX, Sbd + (size_t)(k + 1) * 3 * SS, SS, lane);           // S[k+1].left, used transposed
-            copy_in(sPn, Pbd + (size_t)(k + 1) * 3 * SS + SS, SS, lane);     // Pinv[k+1].main
-            wave_sync();
+        if (has_r) {                                                         // :614-648
+            const T *sX = Sbd + (size_t)(k + 1) * 3 * SS;                    // S[k+1].left, used transposed
             mfma_for_tiles<T, S, S>(lane,
                 [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, true>(sPm, sX, mt, nt, lane, acc); },
-                [&](int r, int cc, T v) { sT[cc * S + r] = v; });
-            wave_sync();
+                [&](int r, int cc, T v) { sT[1][cc * S + r] = v; });
+        }
+        wave_sync();
+        if (has_l) {
+            const T *sPn = Pbd + (size_t)(k - 1) * 3 * SS + SS;              // Pinv[k-1].main
             mfma_for_tiles<T, S, S>(lane,
-                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sT, sPn, mt, nt, lane, acc); },
+                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sT[0], sPn, mt, nt, lane, acc); },
+                [&](int r, int cc, T v) { Pk[cc * S + r] = -v; });
+        }
+        if (has_r) {
+            const T *sPn = Pbd + (size_t)(k + 1) * 3 * SS + SS;              // Pinv[k+1].main
+            mfma_for_tiles<T, S, S>(lane,
+                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sT[1], sPn, mt, nt, lane, acc); },
                 [&](int r, int cc, T v) { Pk[2 * SS + cc * S + r] = -v; });
         }
     }
@@ -749,6 +755,8 @@ template <typename T, int S, int C>
 int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const T *c, T *Sbd, T *Pbd,
                       T *gamma, T *Ginv, bool have_inverses, hipStream_t st)
 {
+    BatchStride bs = batch_stride(d);
+    bs.stair_follows = d.stair_follows;
     if (!have_inverses) {
         const int nblk = (2 * (d.hi() - d.lo()) + 3) / 4;
         hipLaunchKernelGGL((invert_G_kernel<T, S, C>), dim3(nblk < 8192 ? nblk : 8192, d.B), dim3(256), 0, st, Gd, Ginv, d.K,
@@ -756,7 +764,7 @@ int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const
         GATO_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL((schur_kernel<T, S, C>), dim3(knot_grid(d.hi() - d.lo()), d.B), dim3(WAVE), 0, st, Gd, Ginv, Cd, g, c, d.K,
-                       Sbd, Pbd, gamma, batch_stride(d));
+                       Sbd, Pbd, gamma, bs);
     GATO_HIP_CHECK(hipGetLastError());
     return GATO_OK;
 }

@@ -814,7 +814,10 @@ static int assemble(gato_solver *s, int mode, const int *G_row, const int *G_col
             rc = s->ops->convert(s->d, G_row, G_col, G_val, C_row, C_col, C_val, rho, s->G_dense, s->C_dense, s->Ginv, st);
         } else rc = s->ops->add_rho(s->d, G_val, rho, s->G_dense, st);
         if (rc) return rc;
-        if ((rc = s->ops->form_schur(s->d, s->G_dense, C_dense, d_g, d_c, s->Sbd, s->Pbd, s->gamma, s->Ginv, mode == 0, st))) return rc;
+        s->d.stair_follows = s->precon_mode == GATO_PRECON_STAIR;
+        rc = s->ops->form_schur(s->d, s->G_dense, C_dense, d_g, d_c, s->Sbd, s->Pbd, s->gamma, s->Ginv, mode == 0, st);
+        s->d.stair_follows = 0;
+        if (rc) return rc;
         // preconditioner (gato_defines.h:9-10): the Schur stage leaves the block-Jacobi one (main blocks, zeros beside them)
         if (s->precon_mode == GATO_PRECON_BLOCK_JACOBI) return GATO_OK;                       // SS_PRECON = 0 (gato_schur.cuh:965-970)
         if (s->precon_mode == GATO_PRECON_POINT_JACOBI) return s->ops->point_jacobi(s->d, s->Sbd, s->Pbd, st);   // both 0 (:424-428)

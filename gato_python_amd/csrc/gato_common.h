@@ -93,6 +93,7 @@ struct Dims {
     // stage-level entries only: knots [k_lo, k_hi) to work on (k_hi = 0: all).  A rank of a multi-GPU solve assembles
     // just the block rows its PCG shard reads (gato_python_amd/dist.py: assemble_shard)
     int k_lo = 0, k_hi = 0;
+    int stair_follows = 0;      // internal (whole-solve stage path): the Schur launch need not zero the blocks the stair launch writes
     __host__ __device__ int lo() const { return k_lo; }
     __host__ __device__ int hi() const { return k_hi > 0 ? k_hi : K; }
     __host__ __device__ int n() const { return S + C; }
@@ -106,10 +107,11 @@ struct Dims {
 struct BatchStride {
     size_t g, c, bd, sk, n, nnzG, nnzC;     // elements per system: G_dense, C_dense, S/Pinv, gamma/lambda, g/dz, CSR values
     int k_lo, k_hi;                         // knots the launch works on
+    int stair_follows;
 };
 inline BatchStride batch_stride(const Dims &d)
 {
-    return BatchStride{d.g_dense(), d.c_dense(), d.bd(), d.sk(), d.N(), (size_t)d.nnzG, (size_t)d.nnzC, d.lo(), d.hi()};
+    return BatchStride{d.g_dense(), d.c_dense(), d.bd(), d.sk(), d.N(), (size_t)d.nnzG, (size_t)d.nnzC, d.lo(), d.hi(), 0};
 }
 
 // ---- persistent (resident) PCG launch description ------------------------------------------
