@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("S,C,K,R,dt", [(14, 7, 50, 1, np.float64), (14, 7, 50, 2, np.float64), (14, 7, 50, 3, np.float32),
                                         (14, 7, 64, 8, np.float64), (2, 1, 9, 5, np.float64), (32, 16, 24, 4, np.float64),
-                                        (14, 7, 4096, 8, np.float32)])
+                                        (14, 7, 4096, 8, np.float32), (14, 7, 4096, 8, np.float64), (32, 16, 1024, 8, np.float64)])
 def test_shard_kernels_lockstep(S, C, K, R, dt):
     from gato_python_amd.solver import Solver
     s = synth.make_system(S, C, K, seed=13)
