@@ -202,8 +202,11 @@ __global__ __launch_bounds__(WAVE, (AsmWaves<T, S>::v)) void schur_kernel(const 
     // Only what one product hands to the next goes through LDS (phi, BR, theta); the operands that come from memory
     // (A, B, the inverses, q) are read from there by the lanes that feed them to the matrix cores / the FMAs: 4.5 KB of
     // LDS per wave instead of 10.4 KB, i.e. twice the knots in flight per CU - these launches are latency bound.
+    // (S > 16: several MFMA tiles share every operand element, there the operands are staged in LDS as before.)
+    constexpr bool STAGE = S > 16;
     __shared__ T sPhi[SS], sBR[SC], sTh[SS];
     __shared__ T sv[3 * S];
+    __shared__ T stage[STAGE ? 3 * SS + SC + CC + 2 * S + C : 1];
     const int lane = threadIdx.x;
     for (int k = bs.k_lo + blockIdx.x; k < bs.k_hi; k += gridDim.x) {
         T *Sk = Sbd + (size_t)k * 3 * SS;
@@ -229,6 +232,13 @@ __global__ __launch_bounds__(WAVE, (AsmWaves<T, S>::v)) void schur_kernel(const 
         const T *sA = Cd + cm, *sB = Cd + cm + SS;                           // :189-196
         const T *sQim = Ginv + gm, *sRim = Ginv + gm + SS, *sQik = Ginv + gk;
         const T *sq = g + (size_t)(k - 1) * n;                               // q_{k-1}, r_{k-1}, and q_k n further (u_{k-1} is C long)
+        if constexpr (STAGE) {
+            T *a_ = stage, *b_ = a_ + SS, *qm_ = b_ + SC, *qk_ = qm_ + SS, *rm_ = qk_ + SS, *q_ = rm_ + CC;
+            copy_in(a_, sA, SS, lane); copy_in(b_, sB, SC, lane); copy_in(qm_, sQim, SS, lane); copy_in(qk_, sQik, SS, lane);
+            copy_in(rm_, sRim, CC, lane); copy_in(q_, sq, 2 * S + C, lane);
+            sA = a_; sB = b_; sQim = qm_; sQik = qk_; sRim = rm_; sq = q_;
+            wave_sync();
+        }
         // phi = A Q_{k-1}^-1 (:277-285), BR = B R_{k-1}^-1 (:293-301): matrix cores, results to LDS and S[k].left
         mfma_for_tiles<T, S, S>(lane,
             [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sA, sQim, mt, nt, lane, acc); },
@@ -298,34 +308,45 @@ __global__ __launch_bounds__(WAVE) void ss_kernel(const T *__restrict__ Sbd, T *
     Sbd += blockIdx.y * bs.bd; Pbd += blockIdx.y * bs.bd;
     // operands straight from memory, only the intermediate products go through LDS (see schur_kernel); the left and the
     // right pair are independent chains: both first products, then both second products
+    constexpr bool STAGE = S > 16;                                           // as in schur_kernel
     __shared__ T sT[2][SS];
+    __shared__ T stage[STAGE ? 5 * SS : 1];
     const int lane = threadIdx.x;
     for (int k = bs.k_lo + blockIdx.x; k < bs.k_hi; k += gridDim.x) {
         T *Pk = Pbd + (size_t)k * 3 * SS;
         const T *sPm = Pk + SS;
         const bool has_l = k > 0, has_r = k < K - 1;                         // right pair for k < K-1 only (D1)
+        const T *xl = Sbd + (size_t)k * 3 * SS, *xr = Sbd + (size_t)(k + 1) * 3 * SS;      // S[k].left, S[k+1].left
+        const T *pl = Pbd + (size_t)(k - 1) * 3 * SS + SS, *pr = Pbd + (size_t)(k + 1) * 3 * SS + SS;   // Pinv[k-1].main, Pinv[k+1].main
         wave_sync();
+        if constexpr (STAGE) {
+            copy_in(stage, sPm, SS, lane);
+            if (has_l) { copy_in(stage + SS, xl, SS, lane); copy_in(stage + 2 * SS, pl, SS, lane); }
+            if (has_r) { copy_in(stage + 3 * SS, xr, SS, lane); copy_in(stage + 4 * SS, pr, SS, lane); }
+            sPm = stage; xl = stage + SS; pl = stage + 2 * SS; xr = stage + 3 * SS; pr = stage + 4 * SS;
+            wave_sync();
+        }
         if (has_l) {                                                         // :578-611
-            const T *sX = Sbd + (size_t)k * 3 * SS;                          // S[k].left
+            const T *sX = xl;
             mfma_for_tiles<T, S, S>(lane,
                 [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sPm, sX, mt, nt, lane, acc); },
                 [&](int r, int cc, T v) { sT[0][cc * S + r] = v; });
         }
         if (has_r) {                                                         // :614-648
-            const T *sX = Sbd + (size_t)(k + 1) * 3 * SS;                    // S[k+1].left, used transposed
+            const T *sX = xr;                                                // used transposed
             mfma_for_tiles<T, S, S>(lane,
                 [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, true>(sPm, sX, mt, nt, lane, acc); },
                 [&](int r, int cc, T v) { sT[1][cc * S + r] = v; });
         }
         wave_sync();
         if (has_l) {
-            const T *sPn = Pbd + (size_t)(k - 1) * 3 * SS + SS;              // Pinv[k-1].main
+            const T *sPn = pl;
             mfma_for_tiles<T, S, S>(lane,
                 [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sT[0], sPn, mt, nt, lane, acc); },
                 [&](int r, int cc, T v) { Pk[cc * S + r] = -v; });
         }
         if (has_r) {
-            const T *sPn = Pbd + (size_t)(k + 1) * 3 * SS + SS;              // Pinv[k+1].main
+            const T *sPn = pr;
             mfma_for_tiles<T, S, S>(lane,
                 [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sT[1], sPn, mt, nt, lane, acc); },
                 [&](int r, int cc, T v) { Pk[2 * SS + cc * S + r] = -v; });

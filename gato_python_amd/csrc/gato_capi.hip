@@ -165,6 +165,9 @@ struct gato_solver {
         unsigned xepoch;
         int mem_kind;                 // 0 uncached, 1 fine-grained, 2 plain hipMalloc
     } cl;
+    struct { const void *Ginv, *Cd, *g; void *dz; } fz;   // set by the whole-solve entries: dz may ride in the PCG launch
+    int dz_fused;                     // the most recent PCG launch also did the dz back-substitution
+    int no_fuse_dz;                   // option
     unsigned long long **cl_tab;      // device copy of cl.peer (the kernel reads the peers' mirror addresses from it)
 };
 
@@ -434,6 +437,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "true_warm_start")) s->true_warm_start = value;
     else if (!strcmp(name, "timeout_ms")) s->timeout_ms = value > 0 ? value : 2000;
     else if (!strcmp(name, "max_workgroups")) s->max_workgroups = value;
+    else if (!strcmp(name, "no_fuse_dz")) s->no_fuse_dz = value;
     else if (!strcmp(name, "knot_lo") || !strcmp(name, "knot_hi")) {          // stage-level entries: knots [knot_lo, knot_hi)
         if (value < 0 || value > s->d.K) { set_error("%s = %d is outside [0, %d]", name, value, s->d.K); return GATO_EINVAL; }
         (name[5] == 'l' ? s->d.k_lo : s->d.k_hi) = value;
@@ -493,6 +497,7 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "last_asm_fused")) *value = s->last_asm_fused;
     else if (!strcmp(name, "last_semi")) *value = s->last_semi;
     else if (!strcmp(name, "last_fallback")) *value = s->last_fallback;
+    else if (!strcmp(name, "last_dz_fused")) *value = s->dz_fused;
     else if (!strcmp(name, "timeout_ms")) *value = s->timeout_ms;
     else if (!strcmp(name, "precon_mode")) *value = s->precon_mode;
     else if (!strcmp(name, "cluster_mem_kind")) *value = s->cl.on ? s->cl.mem_kind : -1;
@@ -697,6 +702,12 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.final_eta = s->final_eta;
         a.eta_hist = (s->record_eta && max_iters <= GATO_ETA_HIST_MAX) ? s->eta_hist : nullptr;
         a.timeout_ticks = (unsigned long long)s->timeout_ms * 100000ull;   // s_memrealtime runs at 100 MHz
+        // one workgroup (per system) holds every lambda_k: the dz back-substitution rides in the same launch
+        s->dz_fused = 0;
+        if (s->fz.dz && !s->no_fuse_dz && groups == 1 && !cg1 && !s->plan_pair && !a.semi && !s->stamp_pcg) {
+            a.dz_Ginv = s->fz.Ginv; a.dz_Cd = s->fz.Cd; a.dz_g = s->fz.g; a.dz = s->fz.dz; a.C = s->d.C;
+            s->dz_fused = 1;
+        }
         a.ablate = s->ablate;
         a.stamps = s->stamp_pcg ? (unsigned long long *)s->sw.scalars + 8 : nullptr;
         a.ev_start = s->time_pcg ? s->ev_pcg0 : nullptr;
@@ -717,6 +728,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
     }
     s->last_stream = st;
     s->last_mode = GATO_PCG_STREAMING; s->last_groups = 0; s->last_threads = 0; s->last_semi = 0;
+    s->dz_fused = 0;
     s->sw.warm_start = s->true_warm_start;
     s->sw.eta_hist = (s->record_eta && max_iters <= GATO_ETA_HIST_MAX) ? s->eta_hist : nullptr;
     if (s->time_pcg) GATO_HIP_CHECK(hipEventRecord(s->ev_pcg0, st));
@@ -739,6 +751,7 @@ extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, con
     if (fits && groups == 1 && s->pcg_mode != GATO_PCG_STREAMING)
         return pcg_one(s, d_S, d_Pinv, d_gamma, d_lambda, exit_tol, max_iters, its, B, st);
     const size_t e = s->esz;
+    s->fz.dz = nullptr;                      // system by system: dz stays a launch of its own
     for (int b = 0; b < B; ++b) {
         int rc = pcg_one(s, (const char *)d_S + b * s->d.bd() * e, (const char *)d_Pinv + b * s->d.bd() * e,
                          (const char *)d_gamma + b * s->d.sk() * e, (char *)d_lambda + b * s->d.sk() * e, exit_tol,
@@ -850,9 +863,12 @@ extern "C" int gato_linsys_device(gato_solver *s, const int *d_G_row, const int 
     if ((rc = assemble(s, 0, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, s->C_dense, d_g, d_c, rho, (hipStream_t)stream))) return rc;
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[1], (hipStream_t)stream));
     s->lc = {1, s->Sbd, s->Pbd, s->gamma, s->C_dense, d_g, lam, dz, exit_tol, max_iters};
-    if ((rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream))) return rc;
+    s->fz = {s->Ginv, s->C_dense, d_g, dz};
+    rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream);
+    s->fz = {nullptr, nullptr, nullptr, nullptr};
+    if (rc) return rc;
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[2], (hipStream_t)stream));
-    if ((rc = gato_compute_dz(s, s->Ginv, s->C_dense, d_g, lam, dz, stream))) return rc;
+    if (!s->dz_fused && (rc = gato_compute_dz(s, s->Ginv, s->C_dense, d_g, lam, dz, stream))) return rc;
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[3], (hipStream_t)stream));
     return GATO_OK;
 }
@@ -869,9 +885,12 @@ extern "C" int gato_linsys_device_blocks(gato_solver *s, const void *d_G_blocks,
     if ((rc = assemble(s, 2, nullptr, nullptr, d_G_blocks, nullptr, nullptr, nullptr, d_C_blocks, d_g, d_c, rho, (hipStream_t)stream))) return rc;
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[1], (hipStream_t)stream));
     s->lc = {1, s->Sbd, s->Pbd, s->gamma, d_C_blocks, d_g, lam, dz, exit_tol, max_iters};
-    if ((rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream))) return rc;
+    s->fz = {s->Ginv, d_C_blocks, d_g, dz};
+    rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream);
+    s->fz = {nullptr, nullptr, nullptr, nullptr};
+    if (rc) return rc;
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[2], (hipStream_t)stream));
-    if ((rc = gato_compute_dz(s, s->Ginv, d_C_blocks, d_g, lam, dz, stream))) return rc;
+    if (!s->dz_fused && (rc = gato_compute_dz(s, s->Ginv, d_C_blocks, d_g, lam, dz, stream))) return rc;
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[3], (hipStream_t)stream));
     return GATO_OK;
 }

@@ -138,6 +138,11 @@ struct PcgLaunch {
     int rank, nranks;            // nranks > 1: second hand-off level through the cross-GPU mirrors below
     unsigned long long *xslots;                    // this rank's mirror (fine-grained memory, written by the peers)
     unsigned long long *const *xpeer;              // DEVICE table [nranks]: every rank's mirror as mapped into this process (xpeer[rank] == xslots)
+    // optional: dz back-substitution (compute_dz, gato_schur.cuh:758-867) in the epilogue of a ONE-workgroup launch (the
+    // workgroup holds every lambda_k): Ginv / C_dense / g in the layouts of gato_compute_dz, C = CONTROL_SIZE
+    const void *dz_Ginv, *dz_Cd, *dz_g;
+    void *dz;
+    int C;
     unsigned xepoch0;            // cross-GPU epochs: in lock-step on all ranks (only cluster launches draw from this counter)
     int launch_id;               // > 0; a timed-out hand-off stores it into *status (stale ids of earlier launches are ignored)
     int *iters;                  // device

@@ -590,6 +590,59 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         const int q = tid + e * (int)blockDim.x;
         if (q < n_ext_rows) dL[(size_t)(k0 + xk) * S + q] = xst[0][q];
     }
+    // ---- dz back-substitution in the same launch (one-workgroup launches: every lambda_k is here).  Same formulas and
+    // accumulation order as dz_kernel (gato_assembly.hip; gato_schur.cuh:758-867, D2 fixed): bit-identical results.
+    if constexpr (XR == 0 && !MR) {
+        if (a.dz != nullptr && W == 1) {
+            const int Cn = a.C, n = S + Cn;
+            const size_t gs = (size_t)(S * S + Cn * Cn), cs = (size_t)(S * S + S * Cn), Nn = (size_t)n * K - Cn;
+            const T *__restrict__ Gi = static_cast<const T *>(a.dz_Ginv) + sys * (gs * K - (size_t)Cn * Cn);
+            const T *__restrict__ Cdn = static_cast<const T *>(a.dz_Cd) + sys * (cs * (K - 1));
+            const T *__restrict__ gv = static_cast<const T *>(a.dz_g) + sys * Nn;
+            T *__restrict__ dzo = static_cast<T *>(a.dz) + sys * Nn;
+            const bool last = k == K - 1;
+            __syncthreads();                                                // every wave has left the loop: the windows are free
+            if (active) xs[0][(j + 1) * SP + r_] = lam;                     // lambda window
+            __syncthreads();
+            T tx = (T)0, tu = (T)0;
+            if (active) {
+                if (!last) {
+                    const T *__restrict__ A = Cdn + (size_t)k * cs;
+                    const T *lp = &xs[0][(j + 2) * SP];                    // lambda_{k+1}
+                    T res = (T)0;
+#pragma unroll
+                    for (int t = 0; t < S; ++t) res = gato::fmaT(A[r_ * S + t], lp[t], res);      // A_k^T lambda_{k+1}   :833-838
+                    tx = gv[(size_t)k * n + r_] - (lam + res);                                    // :841-852
+                    if (r_ < Cn) {
+                        const T *__restrict__ B = A + S * S;
+                        T rb = (T)0;
+#pragma unroll
+                        for (int t = 0; t < S; ++t) rb = gato::fmaT(B[r_ * S + t], lp[t], rb);    // B_k^T lambda_{k+1}   :784-789
+                        tu = gv[(size_t)k * n + S + r_] - rb;                                     // :792-796
+                    }
+                } else tx = gv[(size_t)k * n + r_] - lam;                                         // last state row (D2)
+                xs[1][(j + 1) * SP + r_] = tx;
+            }
+            __syncthreads();                                                // lambda_{k+1} has been read everywhere
+            if (active && !last && r_ < Cn) xs[0][(j + 1) * SP + r_] = tu;
+            __syncthreads();
+            if (active) {
+                const T *__restrict__ Qi = Gi + (size_t)k * gs;
+                const T *tv = &xs[1][(j + 1) * SP];
+                T res = (T)0;
+#pragma unroll
+                for (int cc = 0; cc < S; ++cc) res = gato::fmaT(Qi[r_ + cc * S], tv[cc], res);   // Q_k^-1 (...)         :856-865
+                dzo[(size_t)k * n + r_] = res;
+                if (!last && r_ < Cn) {
+                    const T *__restrict__ Ri = Qi + S * S;
+                    const T *uv = &xs[0][(j + 1) * SP];
+                    T ru = (T)0;
+                    for (int cc = 0; cc < Cn; ++cc) ru = gato::fmaT(Ri[r_ + cc * Cn], uv[cc], ru);   // R_k^-1 (...)         :799-808
+                    dzo[(size_t)k * n + S + r_] = ru;
+                }
+            }
+        }
+    }
     if (wg == 0 && tid == 0) {
         a.iters[sys] = aborted ? -1 : iters;      // in-band: a timed-out hand-off is visible without a second call
         if (a.final_eta && sys == 0) *a.final_eta = (double)eta_new;

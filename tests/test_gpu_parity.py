@@ -929,3 +929,33 @@ def test_stage_times_as_data():
     ms = sol.last_stage_ms()
     assert 0.001 < ms["assembly"] < 1.0 and 0.05 < ms["pcg"] < 5.0 and 0.0005 < ms["dz"] < 1.0, ms
     sol.close()
+
+
+@pytest.mark.parametrize("S,C,K,dt,B", [(14, 7, 50, np.float64, 1), (14, 7, 37, np.float64, 1), (14, 7, 50, np.float64, 6), (2, 1, 5, np.float64, 1),
+                                        (32, 16, 7, np.float32, 1), (14, 7, 1, np.float64, 1), (14, 7, 2, np.float32, 3)])
+def test_dz_in_the_pcg_epilogue_is_bit_identical_to_the_dz_launch(S, C, K, dt, B):
+    """One-workgroup PCG launches (and one workgroup per system of a batch) also do the dz back-substitution (compute_dz,
+    gato_schur.cuh:758-867): same formulas and order as dz_kernel, so the results are the same bits."""
+    from gato_python_amd.solver import Solver
+    s = system(S, C, K, seed=5) if K > 1 else synth.blocks_to_csr(*synth.make_blocks(S, C, 1, 5, False))
+    res = {}
+    for nofuse in (0, 1):
+        sol = Solver(S, C, K, dt, batch=B)
+        sol.set_option("no_fuse_dz", nofuse)
+        sol.set_option("no_pair", 1)                      # the two-rows-per-lane fp32 kernel has no dz epilogue
+        if B > 1:
+            dev = sol.upload_batch([s] * B)
+            lam, dz = sol.new(B * S * K), sol.new(B * sol.N)
+            sol.linsys_batched(*dev, 1e-9, 60, s.rho, lam, dz)
+        else:
+            dev = sol.upload_system(s)
+            lam, dz = sol.new(S * K), sol.new(sol.N)
+            sol.linsys(*dev, 1e-9, 60, s.rho, lam, dz)
+        sol.check_status()
+        assert sol.get_option("last_dz_fused") == (0 if nofuse else 1)
+        res[nofuse] = (host(lam).copy(), host(dz).copy())
+        sol.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    lam_o, dz_o, _ = co.linsys_solve(*s.csr_args(), S, C, K, 1e-9, 60, s.rho, dtype=dt)
+    f64 = dt == np.float64
+    assert rel(res[0][1][:len(dz_o)], dz_o) < (1e-9 if f64 else 5e-3)
