@@ -146,6 +146,7 @@ struct gato_solver {
     int precon_mode;                  // option: GATO_PRECON_* (whole-solve entries)
     int time_stages;                  // option: hipEvents around assembly / PCG / dz of the whole-solve entries
     hipEvent_t ev_stage[4];
+    int cluster_flat;                 // option: 1 (default) = flat cluster exchange where it applies, 0 = always two levels
     int max_workgroups;               // option: CUs a persistent launch may count on (0 = all; ranks sharing one GPU in tests)
     int last_fallback;                // the most recent gato_solver_recover re-ran the PCG through the streaming kernels
     struct {                          // arguments of the most recent whole solve, for gato_solver_recover
@@ -161,8 +162,9 @@ struct gato_solver {
         unsigned long long *local;
         unsigned long long *peer[GATO_MAX_RANKS];
         bool opened[GATO_MAX_RANKS];
-        size_t bytes;
+        size_t bytes, flat_off;
         unsigned xepoch;
+        int last_flat;
         int mem_kind;                 // 0 uncached, 1 fine-grained, 2 plain hipMalloc
     } cl;
     struct { const void *Ginv, *Cd, *g; void *dz; } fz;   // set by the whole-solve entries: dz may ride in the PCG launch
@@ -342,6 +344,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     s->xcd_pack = -1;
     s->pcg_semi = -1;
     s->timeout_ms = 2000;
+    s->cluster_flat = 1;
 
     const Dims &d = s->d;
     const size_t e = s->esz;
@@ -438,6 +441,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "timeout_ms")) s->timeout_ms = value > 0 ? value : 2000;
     else if (!strcmp(name, "max_workgroups")) s->max_workgroups = value;
     else if (!strcmp(name, "no_fuse_dz")) s->no_fuse_dz = value;
+    else if (!strcmp(name, "cluster_flat")) s->cluster_flat = value;
     else if (!strcmp(name, "knot_lo") || !strcmp(name, "knot_hi")) {          // stage-level entries: knots [knot_lo, knot_hi)
         if (value < 0 || value > s->d.K) { set_error("%s = %d is outside [0, %d]", name, value, s->d.K); return GATO_EINVAL; }
         (name[5] == 'l' ? s->d.k_lo : s->d.k_hi) = value;
@@ -498,6 +502,7 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "last_semi")) *value = s->last_semi;
     else if (!strcmp(name, "last_fallback")) *value = s->last_fallback;
     else if (!strcmp(name, "last_dz_fused")) *value = s->dz_fused;
+    else if (!strcmp(name, "last_cluster_flat")) *value = s->cl.on ? s->cl.last_flat : 0;
     else if (!strcmp(name, "timeout_ms")) *value = s->timeout_ms;
     else if (!strcmp(name, "precon_mode")) *value = s->precon_mode;
     else if (!strcmp(name, "cluster_mem_kind")) *value = s->cl.on ? s->cl.mem_kind : -1;
@@ -1265,7 +1270,9 @@ extern "C" int gato_cluster_create(gato_solver *s, int rank, int nranks, void *i
     gato_cluster_destroy(s);
     memset(&s->cl, 0, sizeof(s->cl));
     s->cl.rank = rank; s->cl.nranks = nranks; s->cl.k0 = k0; s->cl.k1 = k1;
-    const size_t need = (size_t)2 * pcg_xslot_granules(s->d.S, (int)s->esz) * 8;
+    // two-level area (2 parities), then the flat area: a slot for each of up to 256 workgroups of the whole cluster
+    s->cl.flat_off = align_up((size_t)2 * pcg_xslot_granules(s->d.S, (int)s->esz), 16);
+    const size_t need = (s->cl.flat_off + (size_t)2 * 256 * pcg_slot_granules(s->d.S, (int)s->esz)) * 8;
     s->cl.bytes = need < 65536 ? 65536 : align_up(need, 65536);
     if ((rc = cluster_alloc(s))) return rc;
     s->cl.peer[rank] = s->cl.local;
@@ -1382,6 +1389,24 @@ extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_P
     a.k_begin = s->cl.k0; a.k_end = s->cl.k1; a.rank = s->cl.rank; a.nranks = s->cl.nranks;
     a.xslots = s->cl.local;
     a.xpeer = s->cl_tab;
+    // flat exchange when the whole cluster has at most 256 workgroups and every rank runs the plain resident variant:
+    // every rank derives every rank's geometry from the same rule (same device type, same options on all ranks)
+    a.flat = 0;
+    if (s->cluster_flat != 0 && s->cl.nranks > 1 && !a.semi) {
+        int total = 0, base = 0, ok = 1;
+        const int k0s = s->cl.k0, k1s = s->cl.k1;
+        for (int r = 0; r < s->cl.nranks && ok; ++r) {
+            int g = 0, t = 0, kp = 0;
+            gato_cluster_knot_range(s->d.K, r, s->cl.nranks, &s->cl.k0, &s->cl.k1);
+            if (!cluster_plan(s, &g, &t, &kp) || s->plan_semi) ok = 0;
+            if (r < s->cl.rank) base += g;
+            total += g;
+        }
+        s->cl.k0 = k0s; s->cl.k1 = k1s;
+        { int g = 0, t = 0, kp = 0; cluster_plan(s, &g, &t, &kp); }       // restore this rank's plan state (plan_semi)
+        if (ok && total <= 256) { a.flat = 1; a.flat_groups = total; a.flat_base = base; a.flat_off = s->cl.flat_off; }
+    }
+    s->cl.last_flat = a.flat;
     a.ev_start = s->time_pcg ? s->ev_pcg0 : nullptr;
     a.ev_stop = s->time_pcg ? s->ev_pcg1 : nullptr;
     s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT; s->last_variant = 0;

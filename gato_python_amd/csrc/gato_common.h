@@ -143,6 +143,11 @@ struct PcgLaunch {
     const void *dz_Ginv, *dz_Cd, *dz_g;
     void *dz;
     int C;
+    // flat variant of the cluster exchange (ranks x workgroups <= 256): every workgroup stores its partial straight into
+    // every rank's mirror and its boundary blocks into its own and (at the rank's edges) the neighbour's - ONE level, no
+    // wait for the rank's own gather first.  The flat area follows the two-level area in every mirror.
+    int flat, flat_groups, flat_base;
+    size_t flat_off;             // granules from the start of a mirror to its flat area
     unsigned xepoch0;            // cross-GPU epochs: in lock-step on all ranks (only cluster launches draw from this counter)
     int launch_id;               // > 0; a timed-out hand-off stores it into *status (stale ids of earlier launches are ignored)
     int *iters;                  // device

@@ -220,11 +220,12 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     unsigned xepoch = MR ? a.xepoch0 : 0u;
     // mirrors of the peers, read once from the device table: the neighbouring ranks' (edge blocks) and, in lane r of
     // wave 0 of workgroup 0, rank r's (the rank total goes to every rank)
-    gu64 *xp_prev = nullptr, *xp_next = nullptr, *xp_lane = nullptr;
+    gu64 *xp_prev = nullptr, *xp_next = nullptr, *xp_lane = nullptr, *xp_all = nullptr;
     if constexpr (MR) {
         if (a.rank > 0) xp_prev = (gu64 *)a.xpeer[a.rank - 1];
         if (a.rank < R - 1) xp_next = (gu64 *)a.xpeer[a.rank + 1];
         if (wg == 0 && wave == 0 && lane < R) xp_lane = (gu64 *)a.xpeer[lane];
+        if (a.flat && wave == 0 && lane < R) xp_all = (gu64 *)a.xpeer[lane];
     }
 
     if (tid == 0) s_abort = 0;     // the status word is never cleared here: the host matches launch ids (gato_pcg_status)
@@ -442,6 +443,109 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         aborted = s_abort != 0;
     };
 
+    // Flat cluster exchange (MR, a.flat): ONE level across the node.  Every workgroup of every rank has a slot in every
+    // mirror (global workgroup index gw = a.flat_base + wg of a.flat_groups); it stores its partial into ALL mirrors (lane r
+    // -> rank r) and its boundary blocks into its own GPU's mirror and, at the rank's edges, the neighbour's; wave 0 polls
+    // the partials of all workgroups and its two neighbours' blocks in ITS OWN GPU's mirror.  Same sum order on every
+    // workgroup of every rank.  Against the two-level form this saves the wait for the rank's own gather before anything
+    // crosses the fabric (a hand-off costs one fabric store + one poll instead of level 1 + that).
+    auto allreduce_flat = [&](T val, T prod, T &total) {
+        if constexpr (MR) {
+            ++epoch; ++xepoch;
+            const T ws = wave_sum(prod);
+            T *wp = wpart[xepoch & 1];
+            if (lane == 0) wp[wave] = ws;
+            const int WT = a.flat_groups, gw = a.flat_base + wg;
+            const size_t so = a.flat_off + ((size_t)(xepoch & 1) * WT + gw) * slotG;       // this workgroup's slot in a mirror
+            gu64 *fl = (gu64 *)a.xslots;
+            if (!NR && active) {
+                if (j == 0) {
+                    XGr::store(fl + so + 16 + r_ * GPV, xepoch, val);
+                    if (x_left) XGr::store(xp_prev + so + 16 + r_ * GPV, xepoch, val);
+                }
+                if (j == nk - 1) {
+                    XGr::store(fl + so + 16 + (S + r_) * GPV, xepoch, val);
+                    if (x_right) XGr::store(xp_next + so + 16 + (S + r_) * GPV, xepoch, val);
+                }
+            }
+            __syncthreads();                                                   // B1
+            if constexpr (NR) {
+                if (tid < 2 * S) {
+                    const T v2 = tid < S ? xst[1][tid] : xst[1][(nk - 1) * S + (tid - S)];
+                    XGr::store(fl + so + 16 + tid * GPV, xepoch, v2);
+                    if (tid < S && x_left) XGr::store(xp_prev + so + 16 + tid * GPV, xepoch, v2);
+                    if (tid >= S && x_right) XGr::store(xp_next + so + 16 + tid * GPV, xepoch, v2);
+                }
+            }
+            if (wave == 0) {
+                T tot = wave_sum(lane < nwaves ? wp[lane] : (T)0);
+                if (lane < R) XGr::store(xp_all + so, xepoch, tot);               // the partial goes into EVERY mirror
+                gu64 *pbase = fl + a.flat_off + (size_t)(xepoch & 1) * WT * slotG;
+                const bool want_l = has_left && lane < S;
+                const bool want_r = has_right && lane >= 32 && lane < 32 + S;
+                gu64 *hptr = want_l ? pbase + (size_t)(gw - 1) * slotG + 16 + (S + lane) * GPV
+                           : want_r ? pbase + (size_t)(gw + 1) * slotG + 16 + (lane - 32) * GPV
+                                    : pbase + (size_t)gw * slotG;
+                gu64 *pptr[Cfg::PM];
+#pragma unroll
+                for (int m = 0; m < Cfg::PM; ++m) pptr[m] = pbase + (size_t)min(lane + 64 * m, WT - 1) * slotG;
+                const int pm_count = (WT + 63) >> 6;
+                unsigned long long raw[Cfg::PM][GPV], hraw[GPV];
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                bool fail = false;
+                for (unsigned spin = 0;; ++spin) {
+#pragma unroll
+                    for (int m = 0; m < Cfg::PM; ++m) {
+                        if (m < pm_count) {
+#pragma unroll
+                            for (int g = 0; g < GPV; ++g)
+                                raw[m][g] = __hip_atomic_load(pptr[m] + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < GPV; ++g) hraw[g] = __hip_atomic_load(hptr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    bool ok = true;
+#pragma unroll
+                    for (int m = 0; m < Cfg::PM; ++m) {
+                        if (m < pm_count) {
+#pragma unroll
+                            for (int g = 0; g < GPV; ++g) ok &= (unsigned)(raw[m][g] >> 32) == xepoch;
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < GPV; ++g) ok &= (unsigned)(hraw[g] >> 32) == xepoch;
+                    if (__all(ok)) break;
+                    if ((spin & 255u) == 255u) {
+                        const bool late = __builtin_amdgcn_s_memrealtime() - t0 > t_limit;
+                        const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
+                        if (late || other) { fail = true; break; }
+                    }
+                }
+                T acc = (T)0;
+#pragma unroll
+                for (int m = 0; m < Cfg::PM; ++m)
+                    acc += (m < pm_count && lane + 64 * m < WT) ? XGr::decode(raw[m]) : (T)0;
+                const T hv = XGr::decode(hraw);
+                tot = wave_sum(acc);
+                if (lane < S) gh[0][lane] = want_l ? hv : (T)0;
+                if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = want_r ? hv : (T)0;
+                if (fail && lane == 0) {
+                    __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_abort = 1;
+                }
+                if (lane == 0) bc[xepoch & 1] = tot;
+            }
+            __syncthreads();                                                   // B2
+            total = bc[xepoch & 1];
+            aborted = s_abort != 0;
+        }
+    };
+    const bool flat = MR && a.flat != 0;
+    auto exchange = [&](T val, T prod, T &total) {
+        if (flat) allreduce_flat(val, prod, total);
+        else allreduce_and_halo(val, prod, total);
+    };
+
     // ---- r~ = Pinv r ; p = r~ ; eta = r . r~   (gato_pcg.cuh:316-335) ------------------------
     auto pinv_times = [&](const T *xw) -> T {
         if constexpr (NR) return (T)0;
@@ -486,7 +590,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         }
         if (multi) {
             T dummy;
-            allreduce_and_halo(r, (T)0, dummy);
+            exchange(r, (T)0, dummy);
             if (tid < S) xs[1][tid] = gh[0][tid];
             else if (tid < 2 * S) xs[1][(nk + 1) * SP + (tid - S)] = gh[1][tid - S];
         }
@@ -499,7 +603,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     {
         T prod0 = r * rt;
         if constexpr (XR > 0) prod0 += extra_rows(dP, 1);
-        allreduce_and_halo(rt, prod0, eta);
+        exchange(rt, prod0, eta);
     }
     const bool rec_on = a.eta_hist != nullptr;                 // wave-uniform: one scalar branch when recording is off
     const bool rec = wg == 0 && tid == 0 && sys == 0;
@@ -528,7 +632,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             {
                 T prod = p * ups;
                 if constexpr (XR > 0) prod += extra_rows(dS, 0);
-                allreduce_and_halo(ups, prod, v);
+                exchange(ups, prod, v);
             }
             GATO_STAMP(1)
             if (aborted) break;
@@ -557,7 +661,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             {
                 T prod = r * rt;
                 if constexpr (XR > 0) prod += extra_rows(dP, 1);
-                allreduce_and_halo(rt, prod, eta_new);
+                exchange(rt, prod, eta_new);
             }
             GATO_STAMP(4)
             if (aborted) break;

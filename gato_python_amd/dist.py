@@ -317,6 +317,7 @@ def run_cluster_lockstep(solvers, Sb, Pb, gamma, exit_tol, max_iters):
         cl[r].pcg(Sb, Pb, gamma, exit_tol, max_iters, lam, its[r], stream=streams[r].cuda_stream)
     torch.cuda.synchronize()
     out = [int(i.cpu()[0]) for i in its]
+    run_cluster_lockstep.last_flat = solvers[0].get_option("last_cluster_flat")     # which exchange ran (closing resets it)
     for c in cl:
         c.close()
     return lam, out

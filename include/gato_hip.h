@@ -210,7 +210,9 @@ int gato_shard_pcg_done(gato_solver *s, int *done, void *stream);
  * GPU.  Rank r owns the balanced contiguous knot range gato_cluster_knot_range gives and a MIRROR (a few KB of
  * fine-grained device memory) that the peers write with system-scope stores over xGMI: per hand-off the rank's total
  * goes into every rank's mirror and the rank's boundary blocks into the neighbours'; a rank polls only its own
- * mirror.  Two hand-offs per iteration, no host involvement, no collective library inside the loop.
+ * mirror.  Two hand-offs per iteration, no host involvement, no collective library inside the loop.  While the cluster
+ * has at most 256 workgroups in all the exchange is flat (every workgroup's partial straight into every mirror, option
+ * cluster_flat = 1, default); larger clusters gather inside each GPU first, then across GPUs.
  *   gato_cluster_create   allocates and zeroes the mirror, returns its 64-byte hipIpcMemHandle_t in ipc_handle_out
  *   gato_cluster_connect  ipc_handles = nranks x 64 bytes in rank order (all-gathered by the caller), and / or
  *                         ptrs[r] = the mirror of a rank living in THIS process (gato_cluster_local_mirror);

@@ -33,17 +33,24 @@ def oracle_blocks(S, C, K, dt, seed=13):
                                         (14, 7, 4096, 2, np.float64), (32, 16, 1024, 2, np.float64),
                                         (14, 7, 4096, 8, np.float32), (14, 7, 4096, 8, np.float64),
                                         (32, 16, 1024, 8, np.float64)])
-def test_cluster_ranks_in_one_process(S, C, K, R, dt):
+@pytest.mark.parametrize("flat", [1, 0])
+def test_cluster_ranks_in_one_process(S, C, K, R, dt, flat):
+    """flat = 1: the one-level exchange (every workgroup's partial straight into every mirror; taken whenever ranks x
+    workgroups <= 256); flat = 0: the two-level exchange (what shards beyond 256 workgroups use), forced."""
     from gato_python_amd.solver import Solver
     Sb, Pb, gam = oracle_blocks(S, C, K, dt)
     f64 = dt == np.float64
     tol, mi = (1e-9, 150) if f64 else (1e-4, 60)
     lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, tol, mi)
     sols = [Solver(S, C, K, dt) for _ in range(R)]
+    for x in sols:
+        x.set_option("cluster_flat", flat)
     dS, dP, dg = sols[0].to_device(Sb), sols[0].to_device(Pb), sols[0].to_device(gam)
     lam, its = run_cluster_lockstep(sols, dS, dP, dg, tol, mi)
     for x in sols:
         x.check_status()
+    fits_flat = sum(x.get_option("last_groups") for x in sols) <= 256
+    assert run_cluster_lockstep.last_flat == (1 if flat and fits_flat else 0)
     assert len(set(its)) == 1 and abs(its[0] - it_o) <= (0 if f64 else 2), (its, it_o)
     err = np.abs(lam.cpu().numpy() - lam_o).max() / np.abs(lam_o).max()
     assert err < (1e-9 if f64 else 5e-3), err
