@@ -186,6 +186,20 @@ __global__ __launch_bounds__(256) void invert_G_kernel(const T *__restrict__ Gd,
     }
 }
 
+// XCD-aware workgroup -> (system, knot) map for the one-wave-per-knot launches.  Workgroups are dealt round-robin over
+// the 8 XCDs in launch order, and each XCD has its own L2: with the plain map the knots k-1, k, k+1 - which share
+// Q_{k-1}^-1 (Schur), Pinv[k+-1].main and S[k+1].left (stair), lambda_{k+1} (dz) - sit on three different L2s and every
+// shared block comes from HBM once per reader.  Here the workgroups of one XCD take CONSECUTIVE knots, so the neighbour's
+// blocks are L2 hits.  A placement hint only: any dispatch order gives the same results.
+__device__ __forceinline__ void xcd_knot_map(int &sys, int &kidx)
+{
+    const unsigned total = gridDim.x * gridDim.y, L = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned t8 = total & ~7u;
+    const unsigned M = L < t8 ? (L & 7u) * (t8 >> 3) + (L >> 3) : L;
+    sys = (int)(M / gridDim.x);
+    kidx = (int)(M % gridDim.x);
+}
+
 // ---- A2b: Schur blocks, block-Jacobi main blocks, gamma (gato_schur.cuh:13-460) -----------------
 // waves per SIMD the register allocation must leave room for (one-wave workgroups: latency-bound launches want many knots in flight)
 template <typename T, int S> struct AsmWaves { static constexpr int v = S <= 16 ? (sizeof(T) == 8 ? 4 : 5) : 1; };
@@ -197,8 +211,10 @@ __global__ __launch_bounds__(WAVE, (AsmWaves<T, S>::v)) void schur_kernel(const 
                                                      T *__restrict__ Pbd, T *__restrict__ gamma, BatchStride bs)
 {
     constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C;
-    Gd += blockIdx.y * bs.g; Ginv += blockIdx.y * bs.g; Cd += blockIdx.y * bs.c; g += blockIdx.y * bs.n;
-    c += blockIdx.y * bs.sk; Sbd += blockIdx.y * bs.bd; Pbd += blockIdx.y * bs.bd; gamma += blockIdx.y * bs.sk;
+    int sysi, kidx;
+    xcd_knot_map(sysi, kidx);
+    Gd += sysi * bs.g; Ginv += sysi * bs.g; Cd += sysi * bs.c; g += sysi * bs.n;
+    c += sysi * bs.sk; Sbd += sysi * bs.bd; Pbd += sysi * bs.bd; gamma += sysi * bs.sk;
     // Only what one product hands to the next goes through LDS (phi, BR, theta); the operands that come from memory
     // (A, B, the inverses, q) are read from there by the lanes that feed them to the matrix cores / the FMAs: 4.5 KB of
     // LDS per wave instead of 10.4 KB, i.e. twice the knots in flight per CU - these launches are latency bound.
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(WAVE, (AsmWaves<T, S>::v)) void schur_kernel(const 
     __shared__ T sv[3 * S];
     __shared__ T stage[STAGE ? 3 * SS + SC + CC + 2 * S + C : 1];
     const int lane = threadIdx.x;
-    for (int k = bs.k_lo + blockIdx.x; k < bs.k_hi; k += gridDim.x) {
+    for (int k = bs.k_lo + kidx; k < bs.k_hi; k += gridDim.x) {
         T *Sk = Sbd + (size_t)k * 3 * SS;
         T *Pk = Pbd + (size_t)k * 3 * SS;
         wave_sync();
@@ -305,14 +321,16 @@ template <typename T, int S>
 __global__ __launch_bounds__(WAVE) void ss_kernel(const T *__restrict__ Sbd, T *__restrict__ Pbd, int K, BatchStride bs)
 {
     constexpr int SS = S * S;
-    Sbd += blockIdx.y * bs.bd; Pbd += blockIdx.y * bs.bd;
+    int sysi, kidx;
+    xcd_knot_map(sysi, kidx);
+    Sbd += sysi * bs.bd; Pbd += sysi * bs.bd;
     // operands straight from memory, only the intermediate products go through LDS (see schur_kernel); the left and the
     // right pair are independent chains: both first products, then both second products
     constexpr bool STAGE = S > 16;                                           // as in schur_kernel
     __shared__ T sT[2][SS];
     __shared__ T stage[STAGE ? 5 * SS : 1];
     const int lane = threadIdx.x;
-    for (int k = bs.k_lo + blockIdx.x; k < bs.k_hi; k += gridDim.x) {
+    for (int k = bs.k_lo + kidx; k < bs.k_hi; k += gridDim.x) {
         T *Pk = Pbd + (size_t)k * 3 * SS;
         const T *sPm = Pk + SS;
         const bool has_l = k > 0, has_r = k < K - 1;                         // right pair for k < K-1 only (D1)
@@ -438,7 +456,7 @@ __global__ __launch_bounds__(NT) void gather_kernel(const int *__restrict__ G_ro
                                                     T *__restrict__ Gd, T *__restrict__ Cd, T *__restrict__ Ginv, BatchStride bs)
 {
     constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C, ABS = SS + SC;
-    static_assert(NT >= 2 * WAVE, "two inversions side by side");
+    static_assert(NT % WAVE == 0, "whole waves");
     __shared__ T blk[SS + CC + ABS];                                          // Q_k | R_k | A_k | B_k
     __shared__ int sPtrG[n + 1], sPtrC[S + 1];
     T *sQ = blk, *sR = blk + SS, *sAB = blk + SS + CC;
@@ -488,7 +506,7 @@ __global__ __launch_bounds__(NT) void gather_kernel(const int *__restrict__ G_ro
         if (!last) for (int i = tid; i < ABS; i += NT) Cd[(size_t)k * ABS + i] = sAB[i];
         if (Ginv) {
             if (wave == 0) invert_to<T, S>(sQ, Ginv + gk, lane, (T)1);
-            else if (wave == 1 && !last) invert_to<T, C>(sR, Ginv + gk + SS, lane, (T)1);
+            if (wave == (NT > WAVE ? 1 : 0) && !last) invert_to<T, C>(sR, Ginv + gk + SS, lane, (T)1);
         }
     }
 }
@@ -704,11 +722,13 @@ __global__ __launch_bounds__(WAVE) void dz_kernel(const T *__restrict__ Ginv, co
                                                   int K, T *__restrict__ dz, BatchStride bs)
 {
     constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C;
-    Ginv += blockIdx.y * bs.g; Cd += blockIdx.y * bs.c; g += blockIdx.y * bs.n; lambda += blockIdx.y * bs.sk;
-    dz += blockIdx.y * bs.n;
+    int sysi, kidx;
+    xcd_knot_map(sysi, kidx);
+    Ginv += sysi * bs.g; Cd += sysi * bs.c; g += sysi * bs.n; lambda += sysi * bs.sk;
+    dz += sysi * bs.n;
     __shared__ T sQi[SS], sA[SS], sRi[CC > 0 ? CC : 1], sB[SC > 0 ? SC : 1], sl[2 * S], st[S + C], sg[S + C];
     const int lane = threadIdx.x;
-    for (int k = bs.k_lo + blockIdx.x; k < bs.k_hi; k += gridDim.x) {
+    for (int k = bs.k_lo + kidx; k < bs.k_hi; k += gridDim.x) {
         const bool last = k == K - 1;
         wave_sync();
         copy_in(sQi, Ginv + (size_t)k * (SS + CC), SS, lane);
@@ -753,7 +773,10 @@ template <typename T, int S, int C>
 int launch_convert(const Dims &d, const int *G_row, const int *G_col, const T *G_val, const int *C_row,
                    const int *C_col, const T *C_val, T rho, T *Gd, T *Cd, T *Ginv, hipStream_t st)
 {
-    constexpr int NT = 128;
+    // one wave per knot for the small shapes: the launch is latency bound (two dependent global round trips per knot) and
+    // registers cap the waves per CU, so one-wave workgroups put twice the knots in flight (batch of 25 600 knots in f64:
+    // 118 -> 105 us); the 32 x 32 shapes have 1 568 entries per knot and keep two waves
+    constexpr int NT = S <= 16 ? 64 : 128;
     hipLaunchKernelGGL((gather_kernel<T, S, C, NT>), dim3(d.hi() - d.lo() < (1 << 20) ? d.hi() - d.lo() : (1 << 20), d.B), dim3(NT), 0, st, G_row, G_col,
                        G_val, C_row, C_col, C_val, d.K, rho, Gd, Cd, Ginv, batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
