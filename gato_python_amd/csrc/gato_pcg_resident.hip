@@ -252,6 +252,54 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // product = M x on the extra rows (x = window w: 0 = p, 1 = r); returns this lane's share of x . (M x)
     auto extra_rows = [&](const T *__restrict__ M, int w) -> T {
         T dot = (T)0;
+        if constexpr (NR && S % 2 == 0) {
+            // No resident rows: a lane takes TWO adjacent rows of a knot per trip.  Element (r, c) of a block row sits at
+            // c*S + r, so the pair (r, r+1) of a column is ONE 8-byte (f32) / 16-byte (f64) load: half the load
+            // instructions and half the L1 sector accesses per byte (the 4-byte-per-lane form keeps the L1 at 83 % of
+            // its 64 B/clk - DESIGN.md 3.1), and both rows share the operand-window reads (packed FMAs in f32).
+            typedef T T2 __attribute__((ext_vector_type(2)));
+            typedef typename VecOf<T>::type V;
+            constexpr int VW = VecOf<T>::W, H = S / 2;
+            const int n_pairs = n_ext * H;
+            const int ne2 = (n_pairs + (int)blockDim.x - 1) / (int)blockDim.x;
+#pragma unroll 1
+            for (int e = 0; e < ne2; ++e) {
+                const int qp = tid + e * (int)blockDim.x;
+                const bool on = qp < n_pairs;
+                const int qq = on ? qp : 0;
+                const int jx = xk + qq / H, r0 = 2 * (qq % H);
+                const T *__restrict__ src = M + (size_t)(k0 + jx) * 3 * S * S + r0;
+                T2 m[3 * S];
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) m[c] = *reinterpret_cast<const T2 *>(src + (size_t)c * S);
+                const bool nl = k0 + jx == 0, nr = k0 + jx == K - 1;        // first / last block row of the system
+#pragma unroll
+                for (int c = 0; c < S; ++c) {
+                    if (nl) m[c] = T2{(T)0, (T)0};
+                    if (nr) m[2 * S + c] = T2{(T)0, (T)0};
+                }
+                const T *xw = &xs[w][jx * SP];
+                T2 acc = {(T)0, (T)0};
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+#pragma unroll
+                    for (int i = 0; i < SP / VW; ++i) {
+                        const V v = *reinterpret_cast<const V *>(xw + b * SP + i * VW);
+#pragma unroll
+                        for (int e2 = 0; e2 < VW; ++e2)
+                            if (i * VW + e2 < S) acc = __builtin_elementwise_fma(m[b * S + i * VW + e2], T2{v[e2], v[e2]}, acc);
+                    }
+                }
+                if (on) {
+                    const int q0 = (jx - xk) * S + r0;
+                    xst[1][q0] = acc[0];
+                    xst[1][q0 + 1] = acc[1];
+                    dot = gato::fmaT(xw[SP + r0], acc[0], dot);
+                    dot = gato::fmaT(xw[SP + r0 + 1], acc[1], dot);
+                }
+            }
+            return dot;
+        }
 #pragma unroll 1
         for (int e = 0; e < ne; ++e) {
             const int q = tid + e * (int)blockDim.x;
