@@ -146,14 +146,13 @@ def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, min_seco
     steps_timed = steps * blocks
     sol.check_status()
 
-    # dominant kernel: the PCG launch, HIP events on its stream right around the launch
+    # dominant kernel: the PCG launch AS IT RUNS IN THE STEP (one-workgroup launches also carry the dz back-substitution
+    # in their epilogue), HIP events recorded on its stream right around the launch (gato_pcg_last_ms)
     sol.set_option("time_pcg", 1)
-    Sb = torch.empty(0)
-    import ctypes as ct
     bufs = [sol.buffer_ptr(i) for i in (3, 4, 5)]
     ms = []
     for i in range(pcg_reps + 3):
-        sol.pcg(bufs[0], bufs[1], bufs[2], 0.0, MAX_ITERS, lam=lam, check=False)
+        step()
         v = sol.pcg_last_ms()
         if i >= 3:
             ms.append(v)

@@ -184,14 +184,14 @@ namespace {
 struct InFlight { hipEvent_t ev; int cus; hipStream_t st; int device; };
 std::mutex g_gate_mu;
 std::vector<InFlight> g_inflight;
-std::vector<hipEvent_t> g_free_events;
+std::vector<InFlight> g_free_events;      // recycled events, kept with the device they were created on
 
 int gate_before(int device, int num_cus, int need, hipStream_t st)
 {
     std::lock_guard<std::mutex> lock(g_gate_mu);
     size_t w = 0;
     for (size_t i = 0; i < g_inflight.size(); ++i) {
-        if (hipEventQuery(g_inflight[i].ev) == hipSuccess) g_free_events.push_back(g_inflight[i].ev);
+        if (hipEventQuery(g_inflight[i].ev) == hipSuccess) g_free_events.push_back(g_inflight[i]);
         else g_inflight[w++] = g_inflight[i];
     }
     g_inflight.resize(w);
@@ -209,8 +209,14 @@ int gate_after(int device, int need, hipStream_t st)
 {
     std::lock_guard<std::mutex> lock(g_gate_mu);
     hipEvent_t ev = nullptr;
-    if (!g_free_events.empty()) { ev = g_free_events.back(); g_free_events.pop_back(); }
-    else GATO_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (size_t i = 0; i < g_free_events.size(); ++i)
+        if (g_free_events[i].device == device) {          // an event belongs to the device it was created on
+            ev = g_free_events[i].ev;
+            g_free_events[i] = g_free_events.back();
+            g_free_events.pop_back();
+            break;
+        }
+    if (!ev) GATO_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     GATO_HIP_CHECK(hipEventRecord(ev, st));
     g_inflight.push_back(InFlight{ev, need, st, device});
     return GATO_OK;
@@ -709,7 +715,10 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.timeout_ticks = (unsigned long long)s->timeout_ms * 100000ull;   // s_memrealtime runs at 100 MHz
         // one workgroup (per system) holds every lambda_k: the dz back-substitution rides in the same launch
         s->dz_fused = 0;
-        if (s->fz.dz && !s->no_fuse_dz && groups == 1 && !cg1 && !s->plan_pair && !a.semi && !s->stamp_pcg) {
+        // (batches only: every system's workgroup does its own dz and a launch of 25 600 one-wave workgroups goes away; for
+        //  ONE system the single workgroup is as latency bound as that launch was - measured 11 us in the epilogue against
+        //  5.3 us + a launch gap - unless asked for with no_fuse_dz = -1)
+        if (s->fz.dz && (s->no_fuse_dz < 0 || (!s->no_fuse_dz && batch > 1)) && groups == 1 && !cg1 && !s->plan_pair && !a.semi && !s->stamp_pcg) {
             a.dz_Ginv = s->fz.Ginv; a.dz_Cd = s->fz.Cd; a.dz_g = s->fz.g; a.dz = s->fz.dz; a.C = s->d.C;
             s->dz_fused = 1;
         }

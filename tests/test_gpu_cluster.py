@@ -181,3 +181,44 @@ def test_sharded_assembly_gives_every_rank_the_rows_its_shard_reads(S, C, K, R, 
     assert float((dz - dz1).abs().max()) / float(dz1.abs().max()) < (1e-9 if f64 else 5e-3)
     for x in sols + [one]:
         x.close()
+
+
+@pytest.mark.parametrize("flat", [1, 0])
+def test_cluster_true_warm_start_and_eta_history(flat):
+    """Options of the resident kernel inside a cluster launch: lambda0 given (r0 = gamma - S lambda0: the ghost blocks of
+    r0 cross the ranks through the same hand-off) and the eta history, against one launch on the whole GPU."""
+    from gato_python_amd.dist import ClusterPCG
+    from gato_python_amd.solver import Solver
+    S, C, K, R, dt = 14, 7, 300, 3, np.float64
+    Sb, Pb, gam = oracle_blocks(S, C, K, dt)
+    rng = np.random.default_rng(3)
+    lam0 = 0.1 * rng.standard_normal(S * K)
+    one = Solver(S, C, K, dt)
+    one.set_option("true_warm_start", 1)
+    one.set_option("record_eta", 1)
+    dS, dP, dg = one.to_device(Sb), one.to_device(Pb), one.to_device(gam)
+    l1 = one.to_device(lam0)
+    l1, it1 = one.pcg(dS, dP, dg, 1e-9, 150, lam=l1)
+    n1 = int(it1.cpu()[0])
+    h1 = one.eta_history(n1 + 1)
+    sols = [Solver(S, C, K, dt) for _ in range(R)]
+    for x in sols:
+        x.set_option("true_warm_start", 1)
+        x.set_option("record_eta", 1)
+        x.set_option("cluster_flat", flat)
+    cl = [ClusterPCG(x, r, R, inprocess_peers=True) for r, x in enumerate(sols)]
+    ClusterPCG.connect_inprocess(cl)
+    streams = lockstep_streams(R)
+    lam = one.to_device(lam0)                              # every rank reads its lambda0 (and its ghosts) from the full array
+    its = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(R)]
+    torch.cuda.synchronize()
+    for r in range(R):
+        cl[r].pcg(dS, dP, dg, 1e-9, 150, lam, its[r], stream=streams[r].cuda_stream)
+    torch.cuda.synchronize()
+    assert [int(i.cpu()[0]) for i in its] == [n1] * R
+    assert float((lam - l1).abs().max()) / float(l1.abs().max()) < 1e-9
+    for x in sols:
+        x.check_status()
+        assert np.allclose(x.eta_history(n1 + 1), h1, rtol=1e-9, atol=0)
+    for x in sols + [one]:
+        x.close()

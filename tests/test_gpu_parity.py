@@ -941,7 +941,7 @@ def test_dz_in_the_pcg_epilogue_is_bit_identical_to_the_dz_launch(S, C, K, dt, B
     res = {}
     for nofuse in (0, 1):
         sol = Solver(S, C, K, dt, batch=B)
-        sol.set_option("no_fuse_dz", nofuse)
+        sol.set_option("no_fuse_dz", 1 if nofuse else -1)    # -1: also for one system (default: batches only)
         sol.set_option("no_pair", 1)                      # the two-rows-per-lane fp32 kernel has no dz epilogue
         if B > 1:
             dev = sol.upload_batch([s] * B)
