@@ -37,3 +37,14 @@ def test_knot_ranges():
     assert knot_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
     with pytest.raises(ValueError):
         knot_ranges(2, 3)
+
+
+def test_cluster_setup_fails_on_every_rank_together():
+    """ClusterPCG's collective set-up (handle exchange, mapping, fit check): a failure on ONE rank must surface as
+    ClusterUnavailable on EVERY rank - nobody left waiting in a collective - so that all ranks take the RCCL fallback."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "cluster_host_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count(" ok [") == 2
