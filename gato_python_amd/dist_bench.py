@@ -169,7 +169,6 @@ def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
     if transport == "xgmi":                               # first solve decides: a time-out anywhere sends every rank to RCCL
         ok = True
         try:
-            sol.set_option("timeout_ms", 1000)
             _, _, it0 = step_xgmi()
             torch.cuda.synchronize()
             ok = int(it0.cpu()[0]) == MAX_ITERS
