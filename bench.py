@@ -51,6 +51,7 @@ WORKLOADS = {
 }
 MAX_ITERS = 100
 PCG_VARIANT = 0     # 1 = opt-in single-reduction (Chronopoulos-Gear) resident kernel, sweep entries only
+PCG_SEMI = None     # force a variant of the persistent launch for K beyond the register file (option pcg_semi), sweep entries only
 
 
 def b_iter(S, K, w):
@@ -61,9 +62,10 @@ def dtype_name(dt):
     return "f64" if np.dtype(dt) == np.float64 else "f32"
 
 
-def run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, max_iters=None, variant=0, min_seconds=0.0):
-    global MAX_ITERS, PCG_VARIANT
+def run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, max_iters=None, variant=0, min_seconds=0.0, pcg_semi=None):
+    global MAX_ITERS, PCG_VARIANT, PCG_SEMI
     PCG_VARIANT = variant
+    PCG_SEMI = pcg_semi
     saved = MAX_ITERS
     if max_iters is not None:
         MAX_ITERS = max_iters
@@ -121,6 +123,8 @@ def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, min_seco
         sol.set_option("pcg_mode", pcg_mode)
     if PCG_VARIANT:
         sol.set_option("pcg_variant", PCG_VARIANT)
+    if PCG_SEMI is not None:
+        sol.set_option("pcg_semi", PCG_SEMI)
     dev = sol.upload_system(sysm)
     lam, dz = sol.new(S * K), sol.new(sol.N)
 
@@ -159,7 +163,8 @@ def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, min_seco
     pcg_ms = float(np.mean(ms))
     bytes_launch = b_iter(S, K, np.dtype(dt).itemsize) * MAX_ITERS
     mode = sol.get_option("last_mode")
-    mode_name = {1: "resident", 2: "streaming"}.get(mode) + (" (semi)" if sol.get_option("last_semi") else "")
+    mode_name = {1: "resident", 2: "streaming"}.get(mode) + {0: "", 1: " (semi)", 2: " (semi, no resident rows)",
+                                                             3: " (LDS-DMA ring)"}[sol.get_option("last_semi")]
     groups, threads = sol.get_option("last_groups"), sol.get_option("last_threads")
     floor = None
     if mode == 1 and not PCG_VARIANT and not sol.get_option("last_pair") and not sol.get_option("last_semi"):   # the diagnostic build: plain pcg_resident_kernel
@@ -424,11 +429,12 @@ def main():
         sweep.append(run_batched(14, 7, 50, np.float32, 512, 10, 2, torch))
         r, _ = run_single("iiwa_14_7_k16384_f32", 5, 2, torch, pcg_reps=5)
         sweep.append(annotate(r))
-        # HBM-bound regime (matrices 1.2 GB): 20 iterations per solve keep the run short.  Auto = the semi-resident
-        # persistent launch (one workgroup per CU, 7 % of the block rows in registers, the rest re-read every product);
-        # the streaming kernels (two launches per iteration, LDS-DMA tiles) beside it.
-        for mode, tag in ((None, ""), (2, "_streaming")):
-            r, _ = run_single("iiwa_14_7_k131072_f32", 3, 1, torch, pcg_mode=mode, pcg_reps=5, max_iters=20)
+        # HBM-bound regime (matrices 1.2 GB): 20 iterations per solve keep the run short.  Auto = the persistent launch
+        # whose block rows stream through an LDS-DMA ring (gato_pcg_dma.hip: one workgroup per CU, all vectors in
+        # registers); beside it the semi-resident persistent launch (7 % of the block rows in registers, the rest re-read
+        # by plain loads every product) and the streaming kernels (two launches per iteration, LDS-DMA tiles).
+        for mode, semi, tag in ((None, None, ""), (None, 1, "_semi"), (2, None, "_streaming")):
+            r, _ = run_single("iiwa_14_7_k131072_f32", 3, 1, torch, pcg_mode=mode, pcg_reps=5, max_iters=20, pcg_semi=semi)
             annotate(r, "iiwa_14_7_k131072_f32" + tag)
             r["workload"] += tag
             r["max_iters"] = 20

@@ -51,6 +51,8 @@ static Ops make_ops(int dtype)
     };
     o.pcg_plan = [](PcgPlan *p) { return pcg_resident_plan<T, S>(p); };
     o.pcg_resident = [](const PcgLaunch &a, hipStream_t st) { return launch_pcg_resident<T, S>(a, st); };
+    o.pcg_dma_max_knots = []() { return pcg_dma_max_knots<T, S>(); };
+    o.pcg_dma = [](const PcgLaunch &a, hipStream_t st) { return launch_pcg_dma<T, S>(a, st); };
     o.pcg_cg1_max_threads = []() { return pcg_cg1_max_threads<T, S>(); };
     o.pcg_cg1 = [](const PcgLaunch &a, hipStream_t st) { return launch_pcg_cg1<T, S>(a, st); };
     o.stream_grid = [](int K, int mg) { return stream_grid<T, S>(K, mg); };
@@ -619,12 +621,18 @@ static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int
         const int xt = s->plan.semi_threads, nt = s->plan.nores_threads;
         const bool semi_ok = xt > 0 && (long long)(kp - xt / S) * S <= (long long)s->plan.semi_rows * xt;
         const bool nores_ok = nt > 0 && (long long)kp * S <= (long long)s->plan.nores_rows * nt;
+        // the LDS-DMA ring (option pcg_semi = 3; auto: fp32 once S and Pinv together are well past the 256 MB Infinity Cache,
+        // i.e. the re-read block rows come from HBM - measured cross-over at 14/7 fp32: K ~ 90 000 = 420 MB; below that the
+        // semi-resident launch is served by the caches and wins, and in fp64 the ring's 4-row tiles are step-bound)
+        const bool dma_ok = !s->cl.on && !s->true_warm_start && kp <= s->ops->pcg_dma_max_knots();
+        const bool beyond_cache = s->esz == 4 && 2.0 * (double)s->d.bd() * (double)s->esz > 450e6;
         int which = 0;
         if (s->pcg_semi == 1) which = semi_ok ? 1 : 0;
         else if (s->pcg_semi == 2) which = nores_ok ? 2 : 0;
-        else which = semi_ok ? 1 : (nores_ok ? 2 : 0);
+        else if (s->pcg_semi == 3) which = dma_ok ? 3 : 0;
+        else which = (dma_ok && beyond_cache && K == s->d.K) ? 3 : semi_ok ? 1 : (nores_ok ? 2 : 0);
         if (!which) return 0;
-        *groups = Wx; *threads = which == 1 ? xt : nt; *kpw = kp;
+        *groups = Wx; *threads = which == 1 ? xt : which == 2 ? nt : 512; *kpw = kp;
         s->plan_semi = which;
         return 1;
     }
@@ -736,7 +744,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         const int need_cus = a.xcd_pack > 0 ? s->num_cus : groups;
         int rc;
         if (gated && (rc = gate_before(s->device, s->num_cus, need_cus, st))) return rc;
-        rc = cg1 ? s->ops->pcg_cg1(a, st) : s->ops->pcg_resident(a, st);
+        rc = cg1 ? s->ops->pcg_cg1(a, st) : a.semi == 3 ? s->ops->pcg_dma(a, st) : s->ops->pcg_resident(a, st);
         if (rc == GATO_OK && gated) rc = gate_after(s->device, need_cus, st);
         return rc;
     }

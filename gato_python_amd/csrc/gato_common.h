@@ -128,7 +128,7 @@ struct PcgLaunch {
     int knots_per_wg;            // contiguous knots owned by each workgroup (last may own fewer)
     int groups;                  // W = gridDim.x
     int threads;                 // blockDim.x (multiple of 64, >= knots_per_wg * S unless semi)
-    int semi;                    // 1: semi-resident launch (knots_per_wg exceeds the lanes, the rest are extra rows); 2: no resident rows
+    int semi;                    // 1: semi-resident launch (knots_per_wg exceeds the lanes, the rest are extra rows); 2: no resident rows; 3: LDS-DMA ring (gato_pcg_dma.hip)
     unsigned long long *slots;   // hand-off granules: every 8-byte word {epoch, payload}; epochs only grow, so no re-zeroing
     unsigned epoch0;             // this launch uses epochs epoch0+1 .. (the solver hands out disjoint ranges)
     // knot range [k_begin, k_end) of the system this launch works on (single GPU: 0, K).  Multi-GPU cluster launch
@@ -227,6 +227,9 @@ template <typename T, int S>
 int pcg_resident_plan(PcgPlan *plan);
 template <typename T, int S>
 int launch_pcg_resident(const PcgLaunch &a, hipStream_t st);
+template <typename T, int S> int pcg_dma_max_knots();          // knots per workgroup of the LDS-DMA variant (0: none for this shape)
+template <typename T, int S>
+int launch_pcg_dma(const PcgLaunch &a, hipStream_t st);
 template <typename T, int S> int pcg_cg1_max_threads();
 template <typename T, int S>
 int launch_pcg_cg1(const PcgLaunch &a, hipStream_t st);
@@ -293,6 +296,8 @@ struct Ops {
                       hipStream_t);
     int (*pcg_plan)(PcgPlan *);
     int (*pcg_resident)(const PcgLaunch &, hipStream_t);
+    int (*pcg_dma_max_knots)();
+    int (*pcg_dma)(const PcgLaunch &, hipStream_t);
     int (*pcg_cg1_max_threads)();
     int (*pcg_cg1)(const PcgLaunch &, hipStream_t);
     int (*pcg_streaming)(const Dims &, const void *, const void *, const void *, void *, double, int, int *,

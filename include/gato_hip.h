@@ -86,7 +86,9 @@ void *gato_solver_buffer(gato_solver *s, int which);
  * launches of up to 32 workgroups are placed on one XCD - a placement hint, never needed for correctness; 0 off),
  * asm_mode (whole-solve entries: 0 = auto - convert + Schur + stair as ONE fused launch when K*B <= 2 x CUs, the
  * stage kernels otherwise; 1 = stage kernels; 2 = fused; both give bit-identical buffers), pcg_semi (-1 = auto: K
- * beyond the register file runs as one persistent semi-resident launch; 0 = the streaming kernels), time_pcg (record
+ * beyond the register file runs as one persistent launch - semi-resident, or with the block rows streamed through an
+ * LDS-DMA ring once fp32 matrices are far beyond the Infinity Cache; 0 = the streaming kernels; 1 / 2 / 3 force the
+ * semi-resident launch with / without resident rows / the LDS-DMA ring), time_pcg (record
  * hipEvents around the PCG launch), time_stages (hipEvents around assembly / PCG / dz of the whole-solve entries),
  * precon_mode (GATO_PRECON_*), knot_lo / knot_hi (the stage-level entries gato_convert / gato_form_schur / gato_form_ss /
  * gato_compute_dz then work on the knots [knot_lo, knot_hi) only - a rank of a multi-GPU solve assembles just what its

@@ -17,10 +17,11 @@ rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_issue1 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-sweep > /dev/null 2> $R/gpurun_out/prof_${TAG}_issue1.err || exit 1
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_issue2 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-sweep > /dev/null 2> $R/gpurun_out/prof_${TAG}_issue2.err || exit 1
 echo profile $TAG done
-# cache behaviour of the HBM-bound semi-resident launch (K = 131072 f32, 10 iterations per launch): every counter group in
-# a pass of its own (four TCP/TCC counters in one pass make rocprofv3 abort on gfx950: "exceeds the capabilities of the
-# hardware to collect"); summarised into profiles/<tag>_cache_counters.csv
+# cache behaviour of the HBM-bound persistent launches (K = 131072 f32, 10 iterations per launch: the LDS-DMA ring = auto,
+# and the semi-resident launch): every counter in a pass of its own (four TCP/TCC counters in one pass make rocprofv3 abort
+# on gfx950: "exceeds the capabilities of the hardware to collect"); summarised into profiles/<tag>_cache_counters.csv
 for GRP in "TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TCC_READ_REQ_sum" "TCC_HIT_sum" "TCC_MISS_sum" "TCC_EA0_RDREQ_sum" "TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --pmc $GRP --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_cache_$GRP -- python3 $R/tools/semi_one.py > /dev/null 2> $R/gpurun_out/prof_${TAG}_cache_$GRP.err || echo "pass $GRP failed"
+  rocprofv3 --pmc $GRP --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_cache_$GRP -- python3 $R/tools/semi_one.py 131072 > /dev/null 2> $R/gpurun_out/prof_${TAG}_cache_$GRP.err || echo "pass $GRP failed"
+  rocprofv3 --pmc $GRP --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_cache_semi_$GRP -- python3 $R/tools/semi_one.py 131072 1 > /dev/null 2> $R/gpurun_out/prof_${TAG}_cache_semi_$GRP.err || echo "pass semi $GRP failed"
 done
 echo cache passes $TAG done

@@ -1,4 +1,5 @@
-"""A few semi-resident PCG launches at K = 131072 f32 (for rocprofv3 --pmc passes)."""
+"""A few persistent PCG launches at K = 131072 f32 (for rocprofv3 --pmc passes): argv = [K [pcg_semi]], pcg_semi as the solver
+option (default: auto = the LDS-DMA ring at this size; 1 = semi-resident)."""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -8,6 +9,8 @@ from gato_python_amd.solver import Solver
 S, C, K, dt = 14, 7, int(sys.argv[1]) if len(sys.argv) > 1 else 131072, np.float32
 s = synth.make_system(S, C, K, seed=0)
 sol = Solver(S, C, K, dt)
+if len(sys.argv) > 2:
+    sol.set_option("pcg_semi", int(sys.argv[2]))
 dev = sol.upload_system(s)
 lam, dz = sol.new(S * K), sol.new(sol.N)
 sol.linsys(*dev, 0.0, 10, s.rho, lam, dz)

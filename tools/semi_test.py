@@ -34,7 +34,7 @@ if len(sys.argv) > 1:
 for (S, C, K, dt) in cases:
     b, lb = run(S, C, K, dt, 0)
     line = f"{S}/{C}/{K} {np.dtype(dt).name}: streaming {b['us_per_iter']:.1f}"
-    for semi, name in ((1, "semi-resident"), (2, "no resident rows")):
+    for semi, name in ((1, "semi-resident"), (2, "no resident rows"), (3, "LDS-DMA ring")):
         a, la = run(S, C, K, dt, semi)
         if a["semi"] != semi:
             line += f" | {name}: n/a"

@@ -66,7 +66,7 @@ fetch, write = counter("fetch"), counter("write")
 WL = {"iiwa_14_7_k50_f64": ("pcg_resident_kernel<double, 14", 50), "iiwa_14_7_k50_f32": ("pcg_single_f32x2_kernel<14", 50),
       "iiwa_14_7_k512_f32": ("pcg_resident_kernel<float, 14", 512), "iiwa_14_7_k4096_f32": ("pcg_resident_kernel<float, 14", 4096),
       "iiwa_14_7_k4096_f64": ("pcg_resident_kernel<double, 14", 4096), "s32_c16_k1024_f32": ("pcg_resident_kernel<float, 32", 1024),
-      "iiwa_14_7_k131072_f32": ("pcg_resident_kernel<float, 14", 131072)}
+      "iiwa_14_7_k131072_f32": ("pcg_dma_kernel<float, 14", 131072), "iiwa_14_7_k131072_f32_semi": ("pcg_resident_kernel<float, 14", 131072)}
 bench = one(f"prof_{tag}_bench.json")
 geom = {}
 if bench:
@@ -87,8 +87,8 @@ for name, (prefix, K) in WL.items():
     for key in fetch:
         if key[0].startswith(prefix) and geom.get(name) in (key[1], key[1] // 8 if key[1] % 8 == 0 else -1):   # xcd_pack launches an 8x grid
             fv, wv = fetch[key], write.get(key, [])
-            if ", 16, false" in key[0] and ("iiwa_14_7_k16384_f32" in geom and "iiwa_14_7_k131072_f32" in geom):
-                big = name == "iiwa_14_7_k131072_f32"
+            if ", 16, false" in key[0] and ("iiwa_14_7_k16384_f32" in geom and "iiwa_14_7_k131072_f32_semi" in geom):
+                big = name == "iiwa_14_7_k131072_f32_semi"
                 fv = [v for v in fv if (v >= max(fetch[key]) / 2) == big]
                 wv = [v for v in wv if (v >= max(write[key]) / 2) == big] if wv else wv
             if not fv:
@@ -157,7 +157,7 @@ if rows:
             f.write(f'"{k[0]}",{k[1]},{len(next(iter(v.values())))},' + ",".join(f"{sum(v[n]) / len(v[n]):.0f}" if v.get(n) else "" for n in names) + "\n")
 print("wrote", sorted(os.listdir(out)))
 
-# cache counters of the semi-resident K = 131072 launch: one pass per counter (tools/profile.sh)
+# cache counters of the persistent K = 131072 launches: one pass per counter and kernel (tools/profile.sh)
 cache = {}
 for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_cache_*"))):
     if not os.path.isdir(d):
@@ -166,13 +166,14 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_cache_*"
     if not g:
         continue
     for r in csv.DictReader(open(max(g, key=os.path.getmtime))):
-        if "pcg_resident_kernel" in r["Kernel_Name"]:
-            cache.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for kn, label in (("pcg_dma_kernel", "pcg_dma_kernel (LDS-DMA ring, 256 x 512)"), ("pcg_resident_kernel", "pcg_resident_kernel (semi-resident, 256 x 512)")):
+            if kn in r["Kernel_Name"]:
+                cache.setdefault((label, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
 if cache:
     with open(os.path.join(out, f"{tag}_cache_counters.csv"), "w") as f:
         f.write("kernel,workload,counter,launches,avg_per_launch,note\n")
-        for k, v in sorted(cache.items()):
+        for (label, k), v in sorted(cache.items()):
             v = v[1:] if len(v) > 1 else v            # the first launch also reads the matrices into the register-resident rows
-            f.write(f'"pcg_resident_kernel (semi-resident, 256 x 512)","iiwa 14/7/131072 f32, 10 iterations per launch",{k},{len(v)},{sum(v) / len(v):.0f},'
+            f.write(f'"{label}","iiwa 14/7/131072 f32, 10 iterations per launch",{k},{len(v)},{sum(v) / len(v):.0f},'
                     f'"one rocprofv3 --pmc pass per counter"\n')
     print("wrote cache counters:", sorted(cache))
