@@ -90,7 +90,7 @@ def latency_floor(sol, bufs, lam, production_us):
                 ms.append(sol.pcg_last_ms())
         return 1e3 * float(np.median(ms)) / MAX_ITERS
     try:
-        sol.set_option("stamp_pcg", 1)
+        sol.set_option("stamp_pcg", 2)        # the build with the timing-only switches and no cycle stamps
         full, no_spmv, no_red, nothing = us(0), us(3), us(4), us(15)
     finally:
         sol.set_option("ablate", 0)
@@ -100,9 +100,9 @@ def latency_floor(sol, bufs, lam, production_us):
     out = {"us_per_iteration": floor, "products_us": spmv, "reductions_and_handoffs_us": red,
            "diagnostic_build_full_us": full, "loop_skeleton_us": nothing, "production_us_per_iteration": production_us,
            "frac_of_floor": floor / full if full > 0 else None,
-           "method": "live: diagnostic build of the same kernel (slower than the production build: cycle stamps), ablate = 3 (no "
-                     "products) / 4 (no reductions, no hand-offs) / 15 (loop skeleton); floor = products + reductions; "
-                     "frac_of_floor = floor / full, both in the diagnostic build"}
+           "method": "live: diagnostic build of the same kernel (the production loop plus uniform branches on the timing-only "
+                     "switches; no cycle stamps), ablate = 3 (no products) / 4 (no reductions, no hand-offs) / 15 (loop "
+                     "skeleton); floor = products + reductions; frac_of_floor = floor / full, both in the diagnostic build"}
     W = sol.get_option("last_groups")
     if W > 1:
         # what one all-to-all round of W workgroups costs with no arithmetic at all (tools/micro/pingpong.hip, MI355X)

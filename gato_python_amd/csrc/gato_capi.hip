@@ -731,7 +731,8 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
             s->dz_fused = 1;
         }
         a.ablate = s->ablate;
-        a.stamps = s->stamp_pcg ? (unsigned long long *)s->sw.scalars + 8 : nullptr;
+        a.stamps = s->stamp_pcg == 1 ? (unsigned long long *)s->sw.scalars + 8 : nullptr;
+        a.diag = s->stamp_pcg;
         a.ev_start = s->time_pcg ? s->ev_pcg0 : nullptr;
         a.ev_stop = s->time_pcg ? s->ev_pcg1 : nullptr;
         s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT;

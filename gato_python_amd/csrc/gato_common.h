@@ -70,6 +70,38 @@ __device__ __forceinline__ double lane63(double v)
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+__device__ __forceinline__ float lane0(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+}
+__device__ __forceinline__ double lane0(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 0);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 0);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// Sum of the values in lanes 0..15 (the per-wave partials of a workgroup: at most 16 waves), wave-uniform: the four
+// intra-row steps only - the two row broadcasts of the full wave sum are a third of its dependent chain.
+// every lane ends with the sum of its row of 16 lanes
+template <typename T>
+__device__ __forceinline__ T row_sums_dpp(T v)
+{
+    v += dpp_mov<0xB1, 0xf, true>(v);
+    v += dpp_mov<0x4E, 0xf, true>(v);
+    v += dpp_mov<0x141, 0xf, true>(v);
+    v += dpp_mov<0x140, 0xf, true>(v);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T row0_sum_dpp(T v)
+{
+    v += dpp_mov<0xB1, 0xf, true>(v);
+    v += dpp_mov<0x4E, 0xf, true>(v);
+    v += dpp_mov<0x141, 0xf, true>(v);
+    v += dpp_mov<0x140, 0xf, true>(v);
+    return lane0(v);
+}
 template <typename T>
 __device__ __forceinline__ T wave_sum_dpp(T v)
 {
@@ -157,7 +189,8 @@ struct PcgLaunch {
     unsigned long long timeout_ticks;  // s_memrealtime ticks (100 MHz)
     hipEvent_t ev_start, ev_stop;      // optional: recorded right around the kernel launch
     int ablate;                        // diagnostic: timing-only ablation mask (0 in production)
-    unsigned long long *stamps;        // optional: diagnostic cycle stamps (16 words), selects the STAMP build
+    unsigned long long *stamps;        // optional: diagnostic cycle stamps (16 words), selects the DIAG = 1 build
+    int diag;                          // 2: the build with the timing-only switches (ablate) but no stamps
 };
 
 // Cross-GPU mirror of a cluster launch, per epoch parity (granules): one 128-B line per rank for its total (written by

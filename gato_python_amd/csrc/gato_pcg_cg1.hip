@@ -32,7 +32,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
     constexpr int PM = 256 / 64;
     __shared__ __attribute__((aligned(16))) T xr[(MAXK + 4) * SP];   // r on knots k0-2 .. k1+1   (slot = k - (k0-2))
     __shared__ __attribute__((aligned(16))) T xu[(MAXK + 2) * SP];   // u on knots k0-1 .. k1     (slot = k - (k0-1))
-    __shared__ T wpart[2][2][(MAXT + 63) / 64];
+    __shared__ __attribute__((aligned(32))) T wpart[2][2][4 * ((MAXT + 63) / 64)];
     __shared__ T gw[4][32];                                          // received w blocks: L2, L1, R1, R2
     __shared__ T bc[2][2];
     __shared__ int s_abort;
@@ -100,8 +100,8 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
     // one hand-off: two dots + the neighbours' two boundary blocks of w on each side
     auto exchange = [&](T d0, T d1, T &t0, T &t1) {
         ++epoch;
-        const T w0 = wave_sum(d0), w1 = wave_sum(d1);
-        if (lane == 0) { wpart[epoch & 1][0][wave] = w0; wpart[epoch & 1][1][wave] = w1; }
+        partials_store(wpart[epoch & 1][0], wave, lane, d0);
+        partials_store(wpart[epoch & 1][1], wave, lane, d1);
         gu64 *mine = slots + ((size_t)(epoch & 1) * W + wg) * slotG;
         if (W > 1 && own) {
             const int j = k - k0;                                  // own knot index
@@ -110,13 +110,13 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
         }
         __syncthreads();
         if (W == 1) {
-            t0 = wave_sum(lane < nwaves ? wpart[epoch & 1][0][lane] : (T)0);
-            t1 = wave_sum(lane < nwaves ? wpart[epoch & 1][1][lane] : (T)0);
+            t0 = partials_total(wpart[epoch & 1][0], nwaves, lane);
+            t1 = partials_total(wpart[epoch & 1][1], nwaves, lane);
             return;
         }
         if (wave == 0) {
-            T s0 = wave_sum(lane < nwaves ? wpart[epoch & 1][0][lane] : (T)0);
-            T s1 = wave_sum(lane < nwaves ? wpart[epoch & 1][1][lane] : (T)0);
+            T s0 = partials_total(wpart[epoch & 1][0], nwaves, lane);
+            T s1 = partials_total(wpart[epoch & 1][1], nwaves, lane);
             if (lane == 0) { Gr::store(mine, epoch, s0); Gr::store(mine + GPV, epoch, s1); }
             gu64 *pbase = slots + (size_t)(epoch & 1) * W * slotG;
             // halo: lanes [0,32) fetch from the left neighbour (its last two blocks), [32,64) from the right one
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
             if (aborted) break;
             if (rec) a.eta_hist[it + 1] = (double)gamma_new;
             if (fabs(gamma_new) < tol) { iters = it; break; }               // gato_pcg.cuh:404-411
-            beta = gamma_new / gamma_;
-            alpha = gamma_new / (delta - beta * gamma_new / alpha);
+            beta = quotient(gamma_new, gamma_);
+            alpha = quotient(gamma_new, delta - quotient(beta * gamma_new, alpha));
             gamma_ = gamma_new;
         }
     }

@@ -17,6 +17,31 @@ __device__ __forceinline__ float u2f(unsigned x) { return __uint_as_float(x); }
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) { return wave_sum_dpp(v); }
+// second level of a block sum: the per-wave partials (at most 16) sit in lanes 0..15, zeros elsewhere
+template <typename T>
+__device__ __forceinline__ T partials_sum(T v) { return row0_sum_dpp(v); }
+// Block sum in two levels around ONE barrier, neither of which walks the whole wave: level 1 sums inside the four DPP rows
+// of a wave (4 steps) and stores the four row sums (wp: 4 entries per wave, 32-byte aligned); after the barrier lane w
+// reads the four of wave w with one vector read, adds them and the (at most 16) wave sums meet in row 0 (4 steps).  The
+// two row-broadcast steps + readlane 63 that a full wave sum ends with cost more than all of this (14/7/50 fp64 on one
+// CU: 2.37 -> 2.18 us per iteration with level 2 in row 0, -> see DESIGN.md 3.1 with level 1 in rows as well).
+template <typename T>
+__device__ __forceinline__ void partials_store(T *wp, int wave, int lane, T prod)
+{
+    const T rs = row_sums_dpp(prod);
+    if ((lane & 15) == 0) wp[4 * wave + (lane >> 4)] = rs;
+}
+template <typename T>
+__device__ __forceinline__ T partials_total(const T *wp, int nwaves, int lane)
+{
+    typedef T __attribute__((ext_vector_type(4))) V4;
+    T v = (T)0;
+    if (lane < nwaves) {
+        const V4 q = *reinterpret_cast<const V4 *>(wp + 4 * lane);
+        v = (q[0] + q[1]) + (q[2] + q[3]);
+    }
+    return row0_sum_dpp(v);
+}
 
 // ---- granule transport -------------------------------------------------------------------
 // SCOPE: __HIP_MEMORY_SCOPE_AGENT for hand-offs between the workgroups of one GPU (sc1 stores / loads),
@@ -47,6 +72,35 @@ template <typename T> using Granule = GranuleT<T, __HIP_MEMORY_SCOPE_AGENT>;
 template <typename T> using GranuleSys = GranuleT<T, __HIP_MEMORY_SCOPE_SYSTEM>;
 
 constexpr int pad_to(int x, int m) { return (x + m - 1) / m * m; }
+
+// alpha = eta / v and beta = eta' / eta sit on the critical path of every iteration, in every lane; the IEEE division
+// sequence (v_div_scale, v_rcp, 7 FMAs, v_div_fmas, v_div_fixup) costs 0.09 us each in fp64 on one CU.  Here: quotient
+// of the MANTISSAS (both in [0.5, 1): no range problems whatever the operands) by hardware reciprocal + one Newton step
+// (fp64 only) + the quotient's residual correction, then the exponents back in with ldexp - 8 (6) dependent
+// instructions, branch-free.  Measured at 14/7/50 fp64 on one CU (2.37 us per iteration with IEEE divisions, 2.19 with
+// the divisions replaced by products = the bound): this 2.34; the raw operands instead of the mantissas 2.29 but NaN
+// once eta underflows; raw operands behind a range check with an IEEE fall-back 2.54 (even as a scalar branch); the
+// parts that depend on eta alone hoisted a product ahead (three more live registers in a register-bound kernel) 2.46.
+// Same bits as the IEEE quotient for every finite non-zero operand pair with a normal quotient (tools/micro/fastdiv.hip:
+// 0 of 4 M random pairs per type differ, exponents over the whole range); 0 / d = 0; a zero or non-finite divisor gives
+// NaN where IEEE may give an infinity (v = p.Sp = 0 means p = 0, i.e. eta = 0 and 0 / 0 either way).
+__device__ __forceinline__ double quotient(double n, double d)
+{
+    const double mn = __builtin_amdgcn_frexp_mant(n), md = __builtin_amdgcn_frexp_mant(d);
+    const int ex = __builtin_amdgcn_frexp_exp(n) - __builtin_amdgcn_frexp_exp(d);
+    double x = __builtin_amdgcn_rcp(md);
+    x = fma(x, fma(-md, x, 1.0), x);
+    const double q = mn * x;
+    return __builtin_amdgcn_ldexp(fma(fma(-md, q, mn), x, q), ex);
+}
+__device__ __forceinline__ float quotient(float n, float d)
+{
+    const float mn = __builtin_amdgcn_frexp_mantf(n), md = __builtin_amdgcn_frexp_mantf(d);
+    const int ex = __builtin_amdgcn_frexp_expf(n) - __builtin_amdgcn_frexp_expf(d);
+    const float x = __builtin_amdgcn_rcpf(md);
+    const float q = mn * x;
+    return __builtin_amdgcn_ldexpf(fmaf(fmaf(-md, q, mn), x, q), ex);
+}
 
 // y_row = [L M R]_row . window  - window read from LDS with 16-byte broadcast reads.
 template <typename T, int S, int SP>

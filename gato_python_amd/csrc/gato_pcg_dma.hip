@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
     __shared__ T ghost[2][2][S];           // [r | p][left | right]: ghost blocks of the neighbouring workgroups
     __shared__ T gh[2][32];                // neighbours' boundary blocks of the vector just formed
     __shared__ T yedge[2][S];              // own first / last block of it
-    __shared__ T wpart[2][8];
+    __shared__ __attribute__((aligned(32))) T wpart[2][32];
     __shared__ T bc[2];
     __shared__ int s_abort;
 
@@ -196,8 +196,7 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
     // Reduction + halo exchange: the protocol of pcg_resident_kernel (allreduce_and_halo), wave 0 only on the fabric.
     auto exchange = [&](T prod, T &total) {
         ++epoch;
-        const T ws = wave_sum(prod);
-        if (lane == 0) wpart[epoch & 1][wave] = ws;
+        partials_store(wpart[epoch & 1], wave, lane, prod);
         // own first / last block of the vector just formed, for the neighbours
 #pragma unroll
         for (int e = 0; e < XR; ++e) {
@@ -209,7 +208,7 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
         }
         __syncthreads();
         if (wave == 0) {
-            T tot = wave_sum(lane < 8 ? wpart[epoch & 1][lane] : (T)0);
+            T tot = partials_total(wpart[epoch & 1], 8, lane);
             gu64 *mine = slots + ((size_t)(epoch & 1) * W + wg) * slotG;
             if (lane < S) Gr::store(mine + 16 + lane * GPV, epoch, yedge[0][lane]);
             else if (lane >= 32 && lane < 32 + S) Gr::store(mine + 16 + (S + lane - 32) * GPV, epoch, yedge[1][lane - 32]);
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
             T v;
             exchange(product(p, 1), v);                                         // upsilon = S p ; v = p . upsilon   (:349-357)
             if (aborted) break;
-            const T alpha = eta / v;                                            // :364
+            const T alpha = quotient(eta, v);                                    // :364
 #pragma unroll
             for (int e = 0; e < XR; ++e) {                                      // :373-377
                 lam[e] += alpha * p[e];
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
             if (aborted) break;
             if (rec) a.eta_hist[it + 1] = (double)eta_new;
             if (fabs(eta_new) < tol) { iters = it; break; }                     // :404-411
-            const T beta = eta_new / eta;                                       // :415
+            const T beta = quotient(eta_new, eta);                               // :415
 #pragma unroll
             for (int e = 0; e < XR; ++e) p[e] = y[e] + beta * p[e];             // :416-419
             if (tid < S) ghost[1][0][tid] = gh[0][tid] + beta * ghost[1][0][tid];

@@ -119,9 +119,12 @@ __device__ __forceinline__ T row_from_memory(const T *__restrict__ src, const T 
 // epoch; totals are summed in rank order (identical on every rank => identical exit decision).  The grid barriers of
 // the reference (gato_pcg.cuh:363,378,393,428) thus become two device-initiated all-gathers per iteration across the
 // node, no host involvement, no collective library inside the loop.
-template <typename T, int S, int MAXT, int NL = 0, bool STAMP = false, int XR = 0, bool NR = false, bool MR = false>
+template <typename T, int S, int MAXT, int NL = 0, int DIAG = 0, int XR = 0, bool NR = false, bool MR = false>
 __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 {
+    // DIAG: 0 = production; 1 = cycle stamps + the timing-only switches of a.ablate; 2 = the switches alone (what
+    // bench.py's latency floor times: the stamps cost registers, and this instantiation has none to spare)
+    constexpr bool STAMP = DIAG == 1, ABL = DIAG != 0;
     typedef ResidentCfg<T, S, MAXT> Cfg;
     typedef Granule<T> Gr;
     typedef GranuleSys<T> XGr;
@@ -130,13 +133,13 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // hand-off layout invariant (DESIGN.md 3.1 dead end 2: granules of two writers in one 128-B line get lost across
     // XCDs): a workgroup's slot is a whole number of 128-B lines (16 granules), the partial has line 0 to itself
     static_assert(MAXT % 64 == 0 && 2 * S * GPV <= 16 * ((2 * S * GPV + 15) / 16), "slot layout");
-    static_assert(!MR || (NL == 0 && !STAMP), "cluster launches use the plain and the semi-resident variants");
+    static_assert(!MR || (NL == 0 && DIAG == 0), "cluster launches use the plain and the semi-resident variants");
 
     constexpr int MAXKX = NR ? Cfg::MAXK * XR : Cfg::MAXK * (1 + XR);          // local knots incl. the extra ones
     static_assert(NL == 0 || XR == 0, "the LDS-tail variant is single-workgroup only");
     static_assert(!NR || (XR > 0 && 2 * S <= 64), "NR: every row is an extra row; wave 0 publishes both boundary blocks");
     __shared__ __attribute__((aligned(16))) T xs[2][(MAXKX + 2) * SP];        // [0] = p window, [1] = r window
-    __shared__ T wpart[2][(MAXT + 63) / 64];   // per-wave partial dots, double-buffered by epoch parity
+    __shared__ __attribute__((aligned(32))) T wpart[2][4 * ((MAXT + 63) / 64)];   // per-wave, per-row partial dots, double-buffered by epoch parity
     typedef typename VecOf<T>::type V;
     constexpr int NREG = 3 * S - NL;
     __shared__ __attribute__((aligned(16))) V ptail[NL > 0 ? NL / VecOf<T>::W : 1][NL > 0 ? MAXT : 1];
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     if (tid == 0) s_abort = 0;     // the status word is never cleared here: the host matches launch ids (gato_pcg_status)
     // test hook, diagnostic build only (options stamp_pcg + ablate = 16): the last workgroup never shows up, as if it
     // had not been scheduled - the others must give up after the time-out and report it
-    if (STAMP && (a.ablate & 16) && W > 1 && wg == W - 1) return;
+    if (ABL && (a.ablate & 16) && W > 1 && wg == W - 1) return;
     for (int i = tid; i < 2 * (MAXKX + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = (T)0;
     __syncthreads();
 
@@ -338,14 +341,13 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // One reduction + halo exchange.  `val` = the vector just produced (upsilon or r~), `prod` the
     // lane's dot contribution.  On return: total in every thread; gh[][] = neighbours' boundary
     // blocks of `val` (zeros where there is no neighbour).
-    const int abl = STAMP ? a.ablate : 0;   // diagnostic timing-only switches, compiled out of the production build
+    const int abl = ABL ? a.ablate : 0;   // diagnostic timing-only switches, compiled out of the production build
     auto allreduce_and_halo = [&](T val, T prod, T &total) {
         ++epoch;
         if constexpr (MR) ++xepoch;
         if (abl & 4) { total = (T)1 + prod * (T)1e-30; return; }
-        const T ws = wave_sum(prod);
         T *wp = wpart[epoch & 1];
-        if (lane == 0) wp[wave] = ws;
+        partials_store(wp, wave, lane, prod);
         gu64 *mine = slots + ((size_t)(epoch & 1) * W + wg) * slotG;
         if (!NR && W > 1 && active) {
             if (j == 0) Gr::store(mine + 16 + r_ * GPV, epoch, val);
@@ -373,11 +375,11 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             // one workgroup: every wave sums the per-wave partials itself (fixed order), no second barrier
             // (one LDS read per lane + a DPP sum: a serial loop over the partials would pay one LDS
             //  round trip per wave)
-            total = wave_sum(lane < nwaves ? wp[lane] : (T)0);
+            total = partials_total(wp, nwaves, lane);
             return;
         }
         if (wave == 0) {
-            T tot = wave_sum(lane < nwaves ? wp[lane] : (T)0);
+            T tot = partials_total(wp, nwaves, lane);
             bool fail = false;
             if (W > 1) {
                 if (lane == 0) Gr::store(mine, epoch, tot);
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                             if (late || other) { fail = true; break; }
                         }
                     }
-                    tot = wave_sum(lane < R ? XGr::decode(traw) : (T)0);     // rank order, the same tree on every GPU
+                    tot = partials_sum(lane < R ? XGr::decode(traw) : (T)0);     // rank order, the same tree on every GPU
                     const T xv = XGr::decode(xraw);
                     if (xw_l) gh[0][lane] = xv;
                     if (xw_r) gh[1][lane - 32] = xv;
@@ -500,9 +502,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     auto allreduce_flat = [&](T val, T prod, T &total) {
         if constexpr (MR) {
             ++epoch; ++xepoch;
-            const T ws = wave_sum(prod);
             T *wp = wpart[xepoch & 1];
-            if (lane == 0) wp[wave] = ws;
+            partials_store(wp, wave, lane, prod);
             const int WT = a.flat_groups, gw = a.flat_base + wg;
             const size_t so = a.flat_off + ((size_t)(xepoch & 1) * WT + gw) * slotG;       // this workgroup's slot in a mirror
             gu64 *fl = (gu64 *)a.xslots;
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 }
             }
             if (wave == 0) {
-                T tot = wave_sum(lane < nwaves ? wp[lane] : (T)0);
+                T tot = partials_total(wp, nwaves, lane);
                 if (lane < R) XGr::store(xp_all + so, xepoch, tot);               // the partial goes into EVERY mirror
                 gu64 *pbase = fl + a.flat_off + (size_t)(xepoch & 1) * WT * slotG;
                 const bool want_l = has_left && lane < S;
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             }
             GATO_STAMP(1)
             if (aborted) break;
-            const T alpha = eta / v;                                            // :364
+            const T alpha = quotient(eta, v);                                    // :364
             lam += alpha * p;                                                   // :373-377
             r -= alpha * ups;
             if (active) xs[1][(j + 1) * SP + r_] = r;
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 if (rec) a.eta_hist[it + 1] = (double)eta_new;
             }
             if (fabs(eta_new) < tol) { iters = it; break; }                     // :404-411
-            const T beta = eta_new / eta;                                       // :415
+            const T beta = quotient(eta_new, eta);                               // :415
             p = rt + beta * p;                                                  // :416-419
             if (active) xs[0][(j + 1) * SP + r_] = p;
 #pragma unroll 1
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
     constexpr int MAXK = (MAXT + H - 1) / H;
     static_assert(S % 2 == 0, "two rows per lane need an even STATE_SIZE");
     __shared__ __attribute__((aligned(16))) float xs[2][(MAXK + 2) * SP];
-    __shared__ float wpart[2][(MAXT + 63) / 64];
+    __shared__ __attribute__((aligned(16))) float wpart[2][4 * ((MAXT + 63) / 64)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int K = a.K;
@@ -865,11 +866,10 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
     unsigned epoch = 0;
     auto block_sum = [&](float prod) -> float {
         ++epoch;
-        const float ws = wave_sum(prod);
         float *wp = wpart[epoch & 1];
-        if (lane == 0) wp[wave] = ws;
+        partials_store(wp, wave, lane, prod);
         __syncthreads();
-        return wave_sum(lane < nwaves ? wp[lane] : 0.f);
+        return partials_total(wp, nwaves, lane);
     };
     auto put = [&](float *buf, f32x2 v) {
         if (active) { buf[(j + 1) * SP + r0] = v[0]; buf[(j + 1) * SP + r1] = v[1]; }
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
     for (int it = 0; it < a.max_iters; ++it) {                             // gato_pcg.cuh:348
         ups = times_window(sm, &xs[0][j * SP]);
         const float v = block_sum(p[0] * ups[0] + p[1] * ups[1]);
-        const float alpha = eta / v;
+        const float alpha = quotient(eta, v);
         lam += alpha * p;
         r -= alpha * ups;
         put(xs[1], r);
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         eta_new = block_sum(r[0] * rt[0] + r[1] * rt[1]);
         if (rec) a.eta_hist[it + 1] = (double)eta_new;
         if (fabsf(eta_new) < tol) { iters = it; break; }                   // :404-411
-        const float beta = eta_new / eta;
+        const float beta = quotient(eta_new, eta);
         p = rt + beta * p;
         put(xs[0], p);
         eta = eta_new;
@@ -1079,7 +1079,8 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
     if constexpr (SINGLE_T > 0) {
         if (single_lds) {
             constexpr int NL = SingleCu<T, S>::nl;
-            if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
+            if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, 1>), dim3(nblocks), dim3(a.threads), 0, st, a);
+            else if (a.diag == 2) hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, 2>), dim3(nblocks), dim3(a.threads), 0, st, a);
             else hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, false>), dim3(nblocks), dim3(a.threads), 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
@@ -1087,7 +1088,8 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
         }
     }
     if (mr) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false, 0, false, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
-    else if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
+    else if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 1>), dim3(nblocks), dim3(a.threads), 0, st, a);
+    else if (a.diag == 2) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2>), dim3(nblocks), dim3(a.threads), 0, st, a);
     else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false>), dim3(nblocks), dim3(a.threads), 0, st, a);
     GATO_HIP_CHECK(hipGetLastError());
     if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));

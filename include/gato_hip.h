@@ -93,7 +93,8 @@ void *gato_solver_buffer(gato_solver *s, int which);
  * precon_mode (GATO_PRECON_*), knot_lo / knot_hi (the stage-level entries gato_convert / gato_form_schur / gato_form_ss /
  * gato_compute_dz then work on the knots [knot_lo, knot_hi) only - a rank of a multi-GPU solve assembles just what its
  * PCG shard reads; reset by every whole-solve call), timeout_ms (bound of every in-kernel spin, default 2000), max_workgroups (CUs a
- * persistent launch may count on; 0 = all of the device), no_single_lds / stamp_pcg / stamp_asm / ablate (diagnostics). */
+ * persistent launch may count on; 0 = all of the device), no_single_lds / stamp_pcg (1 = kernel build with cycle stamps and the
+ * timing-only switches of `ablate`, 2 = the switches alone) / stamp_asm / ablate (diagnostics). */
 int gato_solver_set_option(gato_solver *s, const char *name, int value);
 int gato_solver_get_option(gato_solver *s, const char *name, int *value);
 
