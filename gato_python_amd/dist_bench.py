@@ -9,6 +9,8 @@ sharded PCG of exactly 100 iterations + dz (xgmi transport: assembly and dz shar
 Transport of the sharded PCG: "xgmi" = ONE persistent launch per rank with the dot + halo exchange inside the kernel
 (peer stores into IPC-mapped mirrors, gato_cluster_*); if the mirrors cannot be mapped or the first solve times out,
 "rccl" = two launches + two RCCL all-gathers per iteration (gato_shard_pcg_*).  The line says which one ran.
+The riders run as CHILD jobs of the ranks (rider_in_child: own rendezvous, a deadline, results through a file), so that a
+fault or a hang in the cross-GPU exchange cannot take the line with the replicas value down with it.
 --workload sharded_* makes that solve the line itself; --workload batched_* runs 512 systems per rank per call.
 
 GATO_BENCH_ONE_GPU=1 (rehearsal on a 1-GPU box): every rank uses cuda:0, host collectives run over gloo, each rank
@@ -267,6 +269,77 @@ def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def rider_in_child(dist, rank, world, rider, steps, warmup, deadline):
+    """One knot-sharded rider as a CHILD job: every rank starts `python -m gato_python_amd.dist_bench --rider ...` with its
+    own RANK / LOCAL_RANK / WORLD_SIZE and a fresh rendezvous port, waits for it with a deadline and kills exactly the
+    process group it started when the deadline passes.  The in-kernel cross-GPU exchange is the one part of this bench
+    that can fault or hang for reasons outside the process (peer mappings, fabric): the line with the replicas value must
+    be printed whatever happens there, and a Python try/except does not survive a GPU fault or a rank stuck in a
+    collective.  Rank 0's child leaves its JSON in a temporary file."""
+    import signal
+    import subprocess
+    import sys
+    import tempfile
+    port = [_free_port() if rank == 0 else 0]
+    dist.broadcast_object_list(port, src=0)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tmp = tempfile.gettempdir()
+    out_path = os.path.join(tmp, f"gato_rider_{port[0]}_{rider}.json")
+    log_path = os.path.join(tmp, f"gato_rider_{port[0]}_{rider}_rank{rank}.log")
+    # a job of its own: under torch.distributed.run the environment tells init_process_group to join the AGENT's store
+    # (TORCHELASTIC_USE_AGENT_STORE) - on the new port nobody would be serving it; without those variables rank 0 of the
+    # child job hosts its store itself
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env["MASTER_PORT"] = str(port[0])
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "gato_python_amd.dist_bench", "--rider", rider, "--steps", str(steps), "--warmup", str(warmup),
+           "--out", out_path]
+    rc = None
+    with open(log_path, "w") as log:
+        p = subprocess.Popen(cmd, env=env, cwd=root, stdout=log, stderr=subprocess.STDOUT, start_new_session=True)
+        try:
+            rc = p.wait(timeout=deadline)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)          # the session this rank started, nothing else
+            except ProcessLookupError:
+                pass
+            p.wait()
+            rc = "deadline"
+    dist.barrier()
+    res = None
+    if rank == 0:
+        try:
+            res = json.loads(open(out_path).read())
+        except Exception:     # noqa: BLE001
+            tail = ""
+            try:
+                tail = open(log_path).read()[-400:]
+            except OSError:
+                pass
+            res = {"error": f"rider child job did not deliver (exit {rc}, deadline {deadline} s)", "log_tail": tail}
+        for f in (out_path,):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+    try:
+        os.remove(log_path)
+    except OSError:
+        pass
+    return res
+
+
+RIDER_KEYS = ("value", "unit", "ms_per_step", "scaling", "dtype", "config", "pcg_us_per_iter", "roofline", "parity")
+
+
 def main(args):
     import torch
     import torch.distributed as dist
@@ -281,21 +354,36 @@ def main(args):
     else:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     wl = args.workload or ""
+    rider_out = getattr(args, "out", None)
     if wl.startswith("batched"):
         return main_batched(args, torch, dist, rank, local, world)
-    if wl in WORKLOADS:                                           # the knot-sharded solve as the line itself
+    if wl in WORKLOADS:                                           # the knot-sharded solve as the line itself (or a rider's child job)
         out = sharded_leg(args, torch, dist, rank, local, world, wl, args.steps, args.warmup)
+        if rider_out and rank == 0:
+            with open(rider_out + ".tmp", "w") as f:
+                f.write(json.dumps({k: out[k] for k in RIDER_KEYS}))
+            os.replace(rider_out + ".tmp", rider_out)
+            out = None
     else:
         out = replicas_leg(args, torch, dist, rank, local, world)
+        # riders: child jobs (see rider_in_child) unless asked otherwise; a rehearsal on one GPU with more than 3 ranks
+        # would put more processes on the card than a box allows, so it keeps them in this process
+        inproc = os.environ.get("GATO_BENCH_RIDERS_INPROC") == "1" or (ONE_GPU and world > 3)
         riders = {}
         for rider in ("sharded_k4096_f32", "sharded_k262144_f32"):
             if rider == "sharded_k262144_f32" and world < 2:
                 continue                                          # one GPU runs it through the streaming kernels: not a sharding number
-            try:        # the line above must survive whatever happens in a rider (an error raised on every rank alike)
-                big = rider == "sharded_k262144_f32"
-                sh = sharded_leg(args, torch, dist, rank, local, world, rider, 3 if big else min(args.steps, 20), 1 if big else min(args.warmup, 3))
+            big = rider == "sharded_k262144_f32"
+            st, wu = (3, 1) if big else (min(args.steps, 20), min(args.warmup, 3))
+            if not inproc:
+                res = rider_in_child(dist, rank, world, rider, st, wu, 240 if big else 180)
                 if rank == 0:
-                    riders[rider] = {k: sh[k] for k in ("value", "unit", "ms_per_step", "scaling", "dtype", "config", "pcg_us_per_iter", "roofline", "parity")}
+                    riders[rider] = res
+                continue
+            try:        # the line above must survive whatever happens in a rider (an error raised on every rank alike)
+                sh = sharded_leg(args, torch, dist, rank, local, world, rider, st, wu)
+                if rank == 0:
+                    riders[rider] = {k: sh[k] for k in RIDER_KEYS}
             except Exception as e:   # noqa: BLE001
                 if rank == 0:
                     riders[rider] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -303,6 +391,20 @@ def main(args):
             out["sharded"] = riders.get("sharded_k4096_f32")
             if "sharded_k262144_f32" in riders:
                 out["sharded_k262144_f32"] = riders["sharded_k262144_f32"]
-    if rank == 0:
-        print(json.dumps(out))
+    if rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
     dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description="child job of bench.py --gpus N: one knot-sharded rider")
+    ap.add_argument("--rider", required=True, choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    a.workload = a.rider
+    if os.environ.get("GATO_RIDER_TEST_HANG") == "1":             # tests/test_dist_gloo.py: the parent's deadline must end this
+        time.sleep(3600)
+    main(a)

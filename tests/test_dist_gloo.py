@@ -48,3 +48,23 @@ def test_cluster_setup_fails_on_every_rank_together():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count(" ok [") == 2
+
+
+@pytest.mark.parametrize("hang", [0, 1])
+def test_rider_child_jobs_cannot_take_the_bench_line_down(hang):
+    """bench.py --gpus N runs the knot-sharded riders as child jobs of the ranks (dist_bench.rider_in_child).  A child that
+    dies at once (here: no GPU) or never returns (GATO_RIDER_TEST_HANG) must cost at most the deadline, leave an error
+    object on rank 0 and no rank waiting in a collective."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), OMP_NUM_THREADS="1",
+               RIDER_DEADLINE="8" if hang else "120", GATO_RIDER_TEST_HANG=str(hang))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "rider_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("RIDER ")]
+    assert len(line) == 1
+    out = json.loads(line[0][6:])
+    assert "error" in out["res"] and ("deadline" in out["res"]["error"])
+    if hang:
+        assert "exit deadline" in out["res"]["error"] and out["seconds"] < 60
