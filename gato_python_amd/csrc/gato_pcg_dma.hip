@@ -6,8 +6,8 @@
 // row), which keeps the L1 at 83 % of its sector rate and the HBM at 5.5 TB/s.  Here:
 //  * one persistent launch, one workgroup of 8 waves per CU, two hand-offs per iteration - the protocol of
 //    pcg_resident_kernel ({epoch, payload} granules, partial + boundary blocks, ghosts advanced locally);
-//  * the block rows of a workgroup stream through a RING of tiles in LDS (fp32: three tiles of 16 block rows, 37 KB each;
-//    fp64: four of 4 block rows, 18 KB each), filled by global_load_lds_dwordx4 (1 KiB per wave-instruction, no
+//  * the block rows of a workgroup stream through a RING of three 37 KB tiles in LDS (16 block rows in fp32, 8 in fp64),
+//    filled by global_load_lds_dwordx4 (1 KiB per wave-instruction, no
 //    registers, whole cache lines), NB-1 tiles ahead of the one being multiplied.  The ring simply keeps going from the
 //    last tile of S into the first tile of Pinv and back: the matrices do not depend on the hand-off, so the next
 //    product's tiles land while the workgroups wait for each other (the register-load variants drain every CU's load
@@ -29,19 +29,19 @@ struct DmaCfg {
     static constexpr int SP = pad_to(S, VW);
     static constexpr int ROW = 3 * S * S;                               // elements of one block row [left|main|right]
     static constexpr int WL = 448;                                      // worker lanes: waves 1..7
-    // block rows per tile: f32 16 (37 632 B at S = 14, half the worker lanes have a row in a tile, ring of three = 113 KB),
-    // f64 4 (18 816 B, ring of four)
-    static constexpr int TK = sizeof(T) == 4 ? 16 : 4;
+    // 37 632 B per tile at S = 14 in either type (fp32: 16 block rows, half the worker lanes have a row in a tile; fp64: 8
+    // block rows, a quarter), ring of three = 113 KB
+    static constexpr int TK = sizeof(T) == 4 ? 16 : 8;
     static constexpr int TROWS = TK * S;
     static constexpr int SUBS = WL / TROWS;                             // tiles per round of worker lanes
     static constexpr int KPR = WL / S;                                  // knots per round (32)
-    static constexpr int NB = sizeof(T) == 4 ? 3 : 4;
+    static constexpr int NB = 3;
     static constexpr int TILE = TK * ROW;                               // elements
     static constexpr int TILE_BYTES = TILE * (int)sizeof(T);
     static constexpr int PIECES = (TILE_BYTES + 1023) / 1024;           // 1 KiB DMA pieces per tile
     static constexpr int NHI = (PIECES + 6) / 7, NLO = PIECES / 7;      // DMA instructions per tile of a worker wave: NHI or NLO
-    static constexpr int XR = 16;                                       // rounds = rows per worker lane
-    static constexpr int MAXK = XR * KPR;                               // knots per workgroup (512: K <= 131 072 on 256 CUs)
+    static constexpr int XR = sizeof(T) == 4 ? 16 : 8;                  // rounds = rows per worker lane (fp64: the operand window is twice the bytes)
+    static constexpr int MAXK = XR * KPR;                               // knots per workgroup (fp32 512: K <= 131 072 on 256 CUs; fp64 256)
     static constexpr bool OK = WL % S == 0 && WL % TROWS == 0 && KPR % TK == 0 && 2 * S <= 64;
 };
 

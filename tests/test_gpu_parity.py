@@ -677,14 +677,14 @@ def test_kkt_producer_through_the_hip_path(K):
                                             (14, 7, 14000, np.float32, 2), (14, 7, 20011, np.float64, 2), (32, 16, 3001, np.float64, 2),
                                             (2, 1, 140000, np.float32, 2),
                                             (14, 7, 14000, np.float32, 3), (14, 7, 20011, np.float64, 3), (14, 7, 131072, np.float32, 3),
-                                            (14, 7, 13901, np.float32, 3), (14, 7, 65537, np.float64, 3)])
+                                            (14, 7, 13901, np.float32, 3), (14, 7, 65531, np.float64, 3)])
 def test_semi_resident_kernel_matches_the_streaming_kernels(S, C, K, dt, which):
     """K beyond the register file: one persistent launch whose workgroups keep part of their knots' matrix rows in
     registers and re-read the rest from memory every product (gato_pcg_resident.hip, XR > 0), against the streaming
     kernels (two launches per iteration) on the same assembled system: same iterates, same exit iteration.
     which = 1: boundary and leading knots register-resident; 2: the variant without resident rows (what fp64 at S = 32 gets);
     3: the LDS-DMA ring (gato_pcg_dma.hip: vectors in registers, block rows streamed through LDS), including ragged last
-    workgroups and tiles (K = 13901, K = 65537)."""
+    workgroups and tiles (K = 13901, K = 65531)."""
     s = system(S, C, K, 17)
     f64 = dt == np.float64
     res = {}

@@ -6,10 +6,12 @@ import torch
 from gato_python_amd import synth, _lib
 from gato_python_amd.solver import Solver
 
-def run(S, C, K, dt, threads=0, groups=0, mode=0, iters=100, reps=10):
+def run(S, C, K, dt, threads=0, groups=0, mode=0, iters=100, reps=10, opts=None):
     sysm = synth.make_system(S, C, K, seed=0)
     sol = Solver(S, C, K, dt)
     sol.set_option("pcg_threads", threads); sol.set_option("pcg_groups", groups); sol.set_option("pcg_mode", mode)
+    for k, v in (opts or {}).items():
+        sol.set_option(k, v)
     dev = sol.upload_system(sysm)
     lam, dz = sol.new(S * K), sol.new(sol.N)
     try:
