@@ -223,12 +223,12 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     unsigned xepoch = MR ? a.xepoch0 : 0u;
     // mirrors of the peers, read once from the device table: the neighbouring ranks' (edge blocks) and, in lane r of
     // wave 0 of workgroup 0, rank r's (the rank total goes to every rank)
-    gu64 *xp_prev = nullptr, *xp_next = nullptr, *xp_lane = nullptr, *xp_all = nullptr;
+    gu64 *xp_prev = nullptr, *xp_next = nullptr;
+    __shared__ unsigned long long s_xpeer[MR ? GATO_MAX_RANKS : 1];      // the peers' mirrors: lane r of wave 0 fetches rank r's at each hand-off
     if constexpr (MR) {
         if (a.rank > 0) xp_prev = (gu64 *)a.xpeer[a.rank - 1];
         if (a.rank < R - 1) xp_next = (gu64 *)a.xpeer[a.rank + 1];
-        if (wg == 0 && wave == 0 && lane < R) xp_lane = (gu64 *)a.xpeer[lane];
-        if (a.flat && wave == 0 && lane < R) xp_all = (gu64 *)a.xpeer[lane];
+        if (wave == 0 && lane < R) s_xpeer[lane] = (unsigned long long)a.xpeer[lane];   // read back by the same lanes only
     }
 
     if (tid == 0) s_abort = 0;     // the status word is never cleared here: the host matches launch ids (gato_pcg_status)
@@ -387,14 +387,19 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 // back to back from clamped (always valid) addresses and waits once: predicated loads would each
                 // get their own s_waitcnt, i.e. one L2 round trip after the other.
                 gu64 *pbase = slots + (size_t)(epoch & 1) * W * slotG;
-                const bool want_l = loc_left && lane < S;
-                const bool want_r = loc_right && lane >= 32 && lane < 32 + S;
-                gu64 *hptr = want_l ? pbase + (size_t)(wg - 1) * slotG + 16 + (S + lane) * GPV
-                           : want_r ? pbase + (size_t)(wg + 1) * slotG + 16 + (lane - 32) * GPV
+                // The per-lane addresses are re-derived from the lane id at every hand-off, behind an empty asm the compiler
+                // cannot see through: as loop invariants it computes them once for both parities, runs out of registers
+                // and re-loads them from scratch at the head of every hand-off (a memory round trip on the critical path).
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const bool want_l = loc_left && ln < S;
+                const bool want_r = loc_right && ln >= 32 && ln < 32 + S;
+                gu64 *hptr = want_l ? pbase + (size_t)(wg - 1) * slotG + 16 + (S + ln) * GPV
+                           : want_r ? pbase + (size_t)(wg + 1) * slotG + 16 + (ln - 32) * GPV
                                     : mine;
                 gu64 *pptr[Cfg::PM];
 #pragma unroll
-                for (int m = 0; m < Cfg::PM; ++m) pptr[m] = pbase + (size_t)min(lane + 64 * m, W - 1) * slotG;
+                for (int m = 0; m < Cfg::PM; ++m) pptr[m] = pbase + (size_t)min(ln + 64 * m, W - 1) * slotG;
                 const int pm_count = (W + 63) >> 6;           // wave-uniform
                 unsigned long long raw[Cfg::PM][GPV], hraw[GPV];
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -450,12 +455,14 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 if (R > 1 && !fail) {
                     // ---- level 2: across the GPUs of the node.  tot = this rank's total (identical in all its workgroups)
                     const size_t xo = (size_t)(xepoch & 1) * xslotG;
-                    if (wg == 0 && lane < R) XGr::store(xp_lane + xo + a.rank * 16, xepoch, tot);
+                    if (wg == 0 && lane < R) XGr::store((gu64 *)s_xpeer[lane] + xo + a.rank * 16, xepoch, tot);
                     gu64 *xl = (gu64 *)a.xslots + xo;                     // polls stay on THIS GPU's memory
-                    const bool xw_l = x_left && lane < S;
-                    const bool xw_r = x_right && lane >= 32 && lane < 32 + S;
-                    gu64 *tptr = xl + (size_t)min(lane, R - 1) * 16;
-                    gu64 *xhp = xw_l ? xl + xghL + lane * GPV : xw_r ? xl + xghR + (lane - 32) * GPV : tptr;
+                    int l2 = lane;
+                    asm volatile("" : "+v"(l2));
+                    const bool xw_l = x_left && l2 < S;
+                    const bool xw_r = x_right && l2 >= 32 && l2 < 32 + S;
+                    gu64 *tptr = xl + (size_t)min(l2, R - 1) * 16;
+                    gu64 *xhp = xw_l ? xl + xghL + l2 * GPV : xw_r ? xl + xghR + (l2 - 32) * GPV : tptr;
                     unsigned long long traw[GPV], xraw[GPV];
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                     for (unsigned spin = 0;; ++spin) {
@@ -528,16 +535,18 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             }
             if (wave == 0) {
                 T tot = partials_total(wp, nwaves, lane);
-                if (lane < R) XGr::store(xp_all + so, xepoch, tot);               // the partial goes into EVERY mirror
+                if (lane < R) XGr::store((gu64 *)s_xpeer[lane] + so, xepoch, tot);   // the partial goes into EVERY mirror
                 gu64 *pbase = fl + a.flat_off + (size_t)(xepoch & 1) * WT * slotG;
-                const bool want_l = has_left && lane < S;
-                const bool want_r = has_right && lane >= 32 && lane < 32 + S;
-                gu64 *hptr = want_l ? pbase + (size_t)(gw - 1) * slotG + 16 + (S + lane) * GPV
-                           : want_r ? pbase + (size_t)(gw + 1) * slotG + 16 + (lane - 32) * GPV
+                int ln = lane;                                 // re-derived at every hand-off (see allreduce_and_halo)
+                asm volatile("" : "+v"(ln));
+                const bool want_l = has_left && ln < S;
+                const bool want_r = has_right && ln >= 32 && ln < 32 + S;
+                gu64 *hptr = want_l ? pbase + (size_t)(gw - 1) * slotG + 16 + (S + ln) * GPV
+                           : want_r ? pbase + (size_t)(gw + 1) * slotG + 16 + (ln - 32) * GPV
                                     : pbase + (size_t)gw * slotG;
                 gu64 *pptr[Cfg::PM];
 #pragma unroll
-                for (int m = 0; m < Cfg::PM; ++m) pptr[m] = pbase + (size_t)min(lane + 64 * m, WT - 1) * slotG;
+                for (int m = 0; m < Cfg::PM; ++m) pptr[m] = pbase + (size_t)min(ln + 64 * m, WT - 1) * slotG;
                 const int pm_count = (WT + 63) >> 6;
                 unsigned long long raw[Cfg::PM][GPV], hraw[GPV];
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
