@@ -1,4 +1,4 @@
-"""Timing-only ablations of the resident PCG iteration (option `ablate`, STAMP builds): which phase costs what."""
+"""Timing-only ablations of the resident PCG iteration (option `ablate`, diagnostic builds): which phase costs what."""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,7 @@ for (S, C, K, dt, thr) in [(14, 7, 50, np.float32, 0), (14, 7, 50, np.float64, 5
     dev = sol.upload_system(s); lam, dz = sol.new(S * K), sol.new(sol.N)
     sol.linsys(*dev, 0.0, 100, s.rho, lam, dz); torch.cuda.synchronize()
     sol.set_option("time_pcg", 1)
-    sol.set_option("stamp_pcg", 1)      # the ablation switches exist only in the diagnostic (STAMP) build of the kernel
+    sol.set_option("stamp_pcg", 2)      # the ablation switches exist only in the diagnostic builds (2 = switches alone, no cycle stamps)
     b = [sol.buffer_ptr(i) for i in (3, 4, 5)]
     for abl, name in [(0, "full"), (1, "-spmv1"), (3, "-spmv1-spmv2"), (4, "-reductions"), (8, "-B3B6"), (12, "-red-B3B6"), (15, "nothing")]:
         sol.set_option("ablate", abl)
