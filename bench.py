@@ -164,10 +164,12 @@ def _run_single(name, steps, warmup, torch, pcg_mode=None, pcg_reps=20, min_seco
     bytes_launch = b_iter(S, K, np.dtype(dt).itemsize) * MAX_ITERS
     mode = sol.get_option("last_mode")
     mode_name = {1: "resident", 2: "streaming"}.get(mode) + {0: "", 1: " (semi)", 2: " (semi, no resident rows)",
-                                                             3: " (LDS-DMA ring)"}[sol.get_option("last_semi")]
+                                                             3: " (LDS-DMA ring)"}[sol.get_option("last_semi")] + \
+        {0: "", 1: " (one workgroup, 2 rows/lane)", 2: " (one workgroup, mixed 2/1 rows per lane)"}[sol.get_option("last_pair")]
     groups, threads = sol.get_option("last_groups"), sol.get_option("last_threads")
     floor = None
-    if mode == 1 and not PCG_VARIANT and not sol.get_option("last_pair") and not sol.get_option("last_semi"):   # the diagnostic build: plain pcg_resident_kernel
+    # the diagnostic builds (timing-only switches) exist for pcg_resident_kernel and the fp64 mixed-rows kernel (last_pair = 2)
+    if mode == 1 and not PCG_VARIANT and sol.get_option("last_pair") in (0, 2) and not sol.get_option("last_semi"):
         floor = latency_floor(sol, bufs, lam, 1e3 * pcg_ms / MAX_ITERS)
     sol.set_option("time_pcg", 0)
     res = dict(
@@ -311,7 +313,8 @@ def committed_traffic(name, res=None):
         k = e.get("kernel", "")
         if e.get("grid_threads") not in (want, 8 * want):                  # one-XCD launches use an 8x oversubscribed grid
             return None, f"stale: collected on a grid of {e.get('grid_threads')} threads, this run launched {want}"
-        if ("pcg_single_f32x2" not in k) and (fam + ", " + str(res["S"])) not in k:
+        single = ("pcg_single_f32x2" in k and fam == "float") or ("pcg_single_f64m" in k and fam == "double")
+        if not single and (fam + ", " + str(res["S"])) not in k:
             return None, f"stale: collected on {k}"
     return e.get("hbm_bytes_per_launch"), src
 

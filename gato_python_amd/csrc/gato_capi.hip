@@ -586,6 +586,13 @@ static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int
         s->plan_pair = 1;
         return 1;
     }
+    if (t == 0 && g <= 1 && !s->no_pair && !s->no_single_lds && s->plan.mixed_rows > 0 && K * S <= s->plan.mixed_rows && K * S > maxT && s->d.B == 1 &&
+        s->stamp_pcg != 1 && !s->cl.on && K == s->d.K) {
+        // fp64 beyond the register-resident single workgroup: one workgroup, two rows per lane in part of the waves
+        *groups = 1; *threads = s->plan.mixed_threads; *kpw = K;
+        s->plan_pair = 2;
+        return 1;
+    }
     if (t == 0) {
         // auto: one workgroup while the problem fits one CU's registers (no inter-CU traffic at all);
         // otherwise 512-thread workgroups (measured best on MI355X: 2 waves per SIMD hide the LDS latency

@@ -220,6 +220,7 @@ struct PcgPlan {
     int max_knots_per_wg;
     int single_max_threads;   // > max_threads: a one-workgroup variant (Pinv rows partly in LDS) exists up to this size
     int pair_threads;         // > 0: fp32 one-workgroup kernel with two rows per lane, up to this many threads
+    int mixed_rows, mixed_threads;   // > 0: fp64 one-workgroup kernel with two rows per lane in some waves (pcg_single_f64m_kernel)
     int semi_threads;         // > 0: semi-resident variant (extra rows re-read from memory): its workgroup size ...
     int semi_rows;            // ... and the extra rows a lane can take
     int nores_threads;        // > 0: variant without resident rows: workgroup size ...

@@ -931,6 +931,179 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
 }
 
 // threads of the two-rows-per-lane kernel: 2*3S*2 matrix registers + window + state must stay under the cap
+// ---- fp64, one workgroup, MIXED rows per lane (IIWA 14/7/50 in fp64 = BASELINE configs[1]) -------------------------------
+// The one-workgroup loop is bound by its LDS reads: every lane reads the 3S-entry operand window of its knot for each
+// of the two products (16-byte broadcast reads), and 700 rows x 84 doubles do not fit the register file, so part of Pinv
+// lives in LDS as well (pcg_resident_kernel<double, 14, 704, NL = 24>: 54 reads per lane and iteration on 11 waves = 594
+// wave-reads).  Here 8 waves instead of 11: the lanes of the first W2 waves own TWO adjacent rows of a knot each - both
+// rows share every window read, their S rows sit in registers (2 x 3S doubles) and their Pinv rows in LDS as (row a, row b)
+// pairs, one 16-byte read per column - and the other waves own one row each with S and Pinv entirely in registers:
+// 8 x 42 window reads + W2 x 42 Pinv reads = 462 wave-reads per iteration.  Same recurrence, same per-row summation order
+// as every other kernel of the family (a row's 3S products are added left to right); block sums as in partials_store.
+template <int S, int W2, int WT, int DIAG = 0>
+__global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
+{
+    typedef double T;
+    typedef double V2 __attribute__((ext_vector_type(2)));
+    constexpr int SP = pad_to(S, 2), NT = 64 * WT, L2 = 64 * W2, ROWS2 = 2 * L2, MAXROWS = ROWS2 + (NT - L2);
+    constexpr int MAXK = (MAXROWS + S - 1) / S;
+    static_assert(S % 2 == 0 && W2 >= 1 && W2 < WT && WT <= 16, "two adjacent rows of one knot per lane in the first W2 waves");
+    __shared__ __attribute__((aligned(16))) T xs[2][(MAXK + 2) * SP];             // [0] = p window, [1] = r window
+    __shared__ __attribute__((aligned(32))) T wpart[2][4 * WT];
+    __shared__ __attribute__((aligned(16))) V2 ptail[3 * S][L2];                   // Pinv entry c of (row a, row b) of a two-row lane
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool two = wave < W2;                                                    // wave-uniform
+    const int K = a.K;
+    const size_t sys = a.batch > 1 ? blockIdx.x : 0;
+    const int row0 = two ? 2 * tid : ROWS2 + (tid - L2);
+    const int j = row0 / S, r0 = row0 - j * S;                                     // knot, (first) row inside it
+    const bool active = row0 < K * S;
+    const int abl = DIAG ? a.ablate : 0;                                           // timing-only switches of the diagnostic build
+
+    const T *__restrict__ dS = static_cast<const T *>(a.S_bd) + sys * 3 * S * S * K;
+    const T *__restrict__ dP = static_cast<const T *>(a.P_bd) + sys * 3 * S * S * K;
+    const T *__restrict__ dG = static_cast<const T *>(a.gamma) + sys * S * K;
+    T *__restrict__ dL = static_cast<T *>(a.lambda) + sys * S * K;
+
+    // m: two-row lanes [S row a | S row b], one-row lanes [S row | Pinv row]
+    T m[6 * S];
+    {
+        const size_t base = (size_t)(active ? j : 0) * 3 * S * S + r0;
+#pragma unroll
+        for (int c = 0; c < 3 * S; ++c) {
+            const bool ok = active && !(j == 0 && c < S) && !(j == K - 1 && c >= 2 * S);      // gato_utils.cuh:157-174
+            if (two) {
+                const V2 sv = *reinterpret_cast<const V2 *>(dS + base + (size_t)c * S);       // rows r0, r0 + 1: adjacent, 16-byte aligned
+                const V2 pv = *reinterpret_cast<const V2 *>(dP + base + (size_t)c * S);
+                m[c] = ok ? sv[0] : (T)0;
+                m[3 * S + c] = ok ? sv[1] : (T)0;
+                ptail[c][tid] = ok ? pv : V2{0, 0};                                           // own lane only: no barrier
+            } else {
+                m[c] = ok ? dS[base + (size_t)c * S] : (T)0;
+                m[3 * S + c] = ok ? dP[base + (size_t)c * S] : (T)0;
+            }
+        }
+    }
+    for (int i = tid; i < 2 * (MAXK + 2) * SP; i += NT) (&xs[0][0])[i] = (T)0;
+    __syncthreads();
+
+    // y = [L M R]_row . window for the lane's row(s); which = 0: S, 1: Pinv
+    auto times_window = [&](int which, const T *xw) -> V2 {
+        T ya = (T)0, yb = (T)0;
+        if (two) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+#pragma unroll
+                for (int i = 0; i < SP / 2; ++i) {
+                    const V2 v = *reinterpret_cast<const V2 *>(xw + b * SP + i * 2);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int c = b * S + i * 2 + e;
+                        if (i * 2 + e < S) {
+                            if (which == 0) {
+                                ya = gato::fmaT(m[c], v[e], ya);
+                                yb = gato::fmaT(m[3 * S + c], v[e], yb);
+                            } else {
+                                const V2 t = ptail[c][tid];
+                                ya = gato::fmaT(t[0], v[e], ya);
+                                yb = gato::fmaT(t[1], v[e], yb);
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+#pragma unroll
+                for (int i = 0; i < SP / 2; ++i) {
+                    const V2 v = *reinterpret_cast<const V2 *>(xw + b * SP + i * 2);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        if (i * 2 + e < S) ya = gato::fmaT(m[(which ? 3 * S : 0) + b * S + i * 2 + e], v[e], ya);
+                }
+            }
+        }
+        return V2{ya, yb};
+    };
+    unsigned epoch = 0;
+    auto block_sum = [&](T prod) -> T {
+        ++epoch;
+        if (abl & 4) return (T)1 + prod * (T)1e-30;
+        T *wp = wpart[epoch & 1];
+        partials_store(wp, wave, lane, prod);
+        __syncthreads();
+        return partials_total(wp, WT, lane);
+    };
+    auto put = [&](T *buf, V2 v) {
+        if (active) {
+            if (two) *reinterpret_cast<V2 *>(buf + (j + 1) * SP + r0) = v;      // r0 even, SP even: aligned
+            else buf[(j + 1) * SP + r0] = v[0];
+        }
+    };
+    const T *wp_ = &xs[0][j * SP], *wr_ = &xs[1][j * SP];                        // the lane's windows: slot j = left neighbour
+
+    V2 lam = {0, 0}, r = {0, 0};
+    if (active) {
+        r[0] = dG[(size_t)j * S + r0];
+        if (two) r[1] = dG[(size_t)j * S + r0 + 1];
+    }
+    if (a.lambda0) {                                                             // true warm start (opt-in)
+        const T *__restrict__ dL0 = static_cast<const T *>(a.lambda0) + sys * S * K;
+        if (active) {
+            lam[0] = dL0[(size_t)j * S + r0];
+            if (two) lam[1] = dL0[(size_t)j * S + r0 + 1];
+        }
+        put(xs[0], lam);
+        __syncthreads();
+        r -= times_window(0, wp_);
+        __syncthreads();
+    }
+    put(xs[1], r);
+    __syncthreads();
+    V2 rt = times_window(1, wr_);                                                // gato_pcg.cuh:316-335
+    T eta = block_sum(r[0] * rt[0] + r[1] * rt[1]), eta_new = (T)0;
+    const bool rec = a.eta_hist && tid == 0 && sys == 0;
+    if (rec) a.eta_hist[0] = (double)eta;
+    V2 p = rt, ups;
+    put(xs[0], p);
+    __syncthreads();
+    int iters = a.max_iters;
+    const T tol = (T)a.exit_tol;
+    for (int it = 0; it < a.max_iters; ++it) {                                   // gato_pcg.cuh:348
+        ups = (abl & 1) ? p * m[0] : times_window(0, wp_);                       // upsilon = S p         (:349-351)
+        const T v = block_sum(p[0] * ups[0] + p[1] * ups[1]);                    // v = p . upsilon       (:353-357)
+        const T alpha = quotient(eta, v);                                        // :364
+        lam += alpha * p;                                                        // :373-377
+        r -= alpha * ups;
+        put(xs[1], r);
+        if (!(abl & 8)) __syncthreads();
+        rt = (abl & 2) ? r * m[1] : times_window(1, wr_);                        // r~ = Pinv r           (:380-381)
+        eta_new = block_sum(r[0] * rt[0] + r[1] * rt[1]);                        // eta' = r . r~         (:382-394)
+        if (rec) a.eta_hist[it + 1] = (double)eta_new;
+        if (fabs(eta_new) < tol) { iters = it; break; }                          // :404-411
+        const T beta = quotient(eta_new, eta);                                   // :415
+        p = rt + beta * p;                                                       // :416-419
+        put(xs[0], p);
+        eta = eta_new;                                                           // :420
+        if (!(abl & 8)) __syncthreads();
+    }
+    if (active) {                                                                // :433-435
+        dL[(size_t)j * S + r0] = lam[0];
+        if (two) dL[(size_t)j * S + r0 + 1] = lam[1];
+    }
+    if (tid == 0) {
+        a.iters[sys] = iters;
+        if (a.final_eta && sys == 0) *a.final_eta = (double)eta_new;
+    }
+}
+
+// shape of the mixed kernel per STATE_SIZE (0 = none): waves with two rows per lane, waves in all
+template <int S> struct MixedCfg { static constexpr int w2 = 0, wt = 0; };
+template <> struct MixedCfg<14> { static constexpr int w2 = 3, wt = 8; };      // 3 x 128 + 5 x 64 = 704 rows = 50 knots
+template <int S> constexpr int mixed_rows() { return MixedCfg<S>::wt > 0 ? 128 * MixedCfg<S>::w2 + 64 * (MixedCfg<S>::wt - MixedCfg<S>::w2) : 0; }
+
 template <int S> struct PairThreads { static constexpr int v = (12 * S + 3 * S + 48) <= 256 ? 512 : ((12 * S + 3 * S + 48) <= 512 ? 256 : 0); };
 template <> struct PairThreads<14> { static constexpr int v = 512; };     // measured: 248 VGPRs, no spill at the 256 cap
 
@@ -993,6 +1166,8 @@ int pcg_resident_plan(PcgPlan *plan)
     plan->max_knots_per_wg = MaxThreads<T, S>::v / S;
     plan->single_max_threads = SingleCu<T, S>::threads;
     plan->pair_threads = (sizeof(T) == 4 && S % 2 == 0) ? PairThreads<S>::v : 0;
+    plan->mixed_rows = sizeof(T) == 8 ? mixed_rows<S>() : 0;
+    plan->mixed_threads = sizeof(T) == 8 ? 64 * MixedCfg<S>::wt : 0;
     plan->semi_threads = SemiThreads<T, S>::v;
     plan->semi_rows = SemiRows<T, S>::v;
     plan->nores_threads = NoresThreads<T, S>::v;
@@ -1023,6 +1198,21 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
             }
             if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
             hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT>), dim3(a.batch > 1 ? a.batch : 1), dim3(a.threads), 0, st, a);
+            GATO_HIP_CHECK(hipGetLastError());
+            if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
+            return GATO_OK;
+        }
+    }
+    if constexpr (sizeof(T) == 8 && MixedCfg<S>::wt > 0) {
+        if (a.pair == 2) {
+            constexpr int W2 = MixedCfg<S>::w2, WT = MixedCfg<S>::wt;
+            if (mr || a.groups != 1 || a.threads != 64 * WT || a.K * S > mixed_rows<S>() || a.stamps || a.dz) {
+                set_error("pcg_resident(mixed): bad launch K=%d threads=%d", a.K, a.threads);
+                return GATO_EINVAL;
+            }
+            if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
+            if (a.diag == 2) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 2>), dim3(a.batch > 1 ? a.batch : 1), dim3(64 * WT), 0, st, a);
+            else hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 0>), dim3(a.batch > 1 ? a.batch : 1), dim3(64 * WT), 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;

@@ -192,9 +192,12 @@ def test_golden_fp64_whole_solve(golden_dir, name, S, C, K, seed, dq, tol, mi):
     (14, 7, 50, np.float32, dict(no_pair=1)),                     # one workgroup, one row per lane
     (14, 7, 73, np.float32, {}),                                  # largest two-rows-per-lane system
     (2, 1, 400, np.float32, {}),
-    (14, 7, 50, np.float64, {}),                                  # one workgroup, Pinv row tails in LDS
+    (14, 7, 50, np.float64, {}),                                  # one workgroup, two rows per lane in 3 of 8 waves (mixed kernel)
+    (14, 7, 50, np.float64, dict(no_pair=1)),                     # one workgroup, one row per lane, Pinv row tails in LDS (what batches run)
     (14, 7, 50, np.float64, dict(no_single_lds=1)),               # two workgroups (register budget)
-    (14, 7, 37, np.float64, {}),                                  # LDS-tail variant with idle lanes
+    (14, 7, 37, np.float64, {}),                                  # mixed kernel with idle lanes: the last two-row lane's knot continues in one-row lanes
+    (14, 7, 41, np.float64, {}),
+    (14, 7, 37, np.float64, dict(no_pair=1)),                     # LDS-tail variant with idle lanes
     (14, 7, 50, np.float32, dict(pcg_groups=7)),                  # forced ragged split
     (14, 7, 50, np.float64, dict(pcg_threads=64)),                # 4 knots per workgroup, 13 groups
     (14, 7, 512, np.float32, {}),
@@ -245,6 +248,9 @@ def test_pcg_variants_against_oracle(S, C, K, dt, opts):
     assert torch.equal(lam, lam2) and torch.equal(it, it2)
     mode = sol.get_option("last_mode")
     assert mode == opts.get("pcg_mode", _lib.PCG_RESIDENT)
+    if (S, K, f64) in ((14, 50, True), (14, 37, True), (14, 41, True)) and not set(opts) - {"no_pair"}:
+        assert sol.get_option("last_pair") == (0 if opts.get("no_pair") else 2)      # the fp64 mixed-rows kernel is what ran
+        assert sol.get_option("last_groups") == 1 and sol.get_option("last_threads") == (512 if not opts else 64 * ((K * S + 63) // 64))
     if "pcg_groups" in opts:
         assert sol.get_option("last_groups") >= opts["pcg_groups"]
     sol.close()

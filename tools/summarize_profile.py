@@ -45,7 +45,7 @@ if trace:
                 f.write(f'"{k[0]}",{k[1]},{k[2]},{len(g)},{sum(g) / len(g):.0f},{min(g)},{max(g)}\n')
 
 
-DIAG = re.compile(r"pcg_resident_kernel<\w+, \d+, \d+, \d+, (true|1|2),")      # the diagnostic (STAMP) build: bench.py's latency-floor launches
+DIAG = re.compile(r"pcg_resident_kernel<\w+, \d+, \d+, \d+, (true|1|2),|pcg_single_f64m_kernel<\d+, \d+, \d+, [12]>")      # the diagnostic (STAMP) build: bench.py's latency-floor launches
 
 
 def counter(kind):
@@ -63,7 +63,7 @@ def counter(kind):
 
 fetch, write = counter("fetch"), counter("write")
 # bench workloads -> (kernel template prefix, S, dtype) ; grid identifies K
-WL = {"iiwa_14_7_k50_f64": ("pcg_resident_kernel<double, 14", 50), "iiwa_14_7_k50_f32": ("pcg_single_f32x2_kernel<14", 50),
+WL = {"iiwa_14_7_k50_f64": ("pcg_single_f64m_kernel<14", 50), "iiwa_14_7_k50_f32": ("pcg_single_f32x2_kernel<14", 50),
       "iiwa_14_7_k512_f32": ("pcg_resident_kernel<float, 14", 512), "iiwa_14_7_k4096_f32": ("pcg_resident_kernel<float, 14", 4096),
       "iiwa_14_7_k4096_f64": ("pcg_resident_kernel<double, 14", 4096), "s32_c16_k1024_f32": ("pcg_resident_kernel<float, 32", 1024),
       "iiwa_14_7_k131072_f32": ("pcg_dma_kernel<float, 14", 131072), "iiwa_14_7_k131072_f32_semi": ("pcg_resident_kernel<float, 14", 131072)}
