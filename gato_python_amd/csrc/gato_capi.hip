@@ -586,7 +586,7 @@ static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int
         s->plan_pair = 1;
         return 1;
     }
-    if (t == 0 && g <= 1 && !s->no_pair && !s->no_single_lds && s->plan.mixed_rows > 0 && K * S <= s->plan.mixed_rows && K * S > maxT && s->d.B == 1 &&
+    if (t == 0 && g <= 1 && !s->no_pair && !s->no_single_lds && s->plan.mixed_rows > 0 && K * S <= s->plan.mixed_rows && K * S > maxT &&
         s->stamp_pcg != 1 && !s->cl.on && K == s->d.K) {
         // fp64 beyond the register-resident single workgroup: one workgroup, two rows per lane in part of the waves
         *groups = 1; *threads = s->plan.mixed_threads; *kpw = K;
@@ -733,7 +733,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         // (batches only: every system's workgroup does its own dz and a launch of 25 600 one-wave workgroups goes away; for
         //  ONE system the single workgroup is as latency bound as that launch was - measured 11 us in the epilogue against
         //  5.3 us + a launch gap - unless asked for with no_fuse_dz = -1)
-        if (s->fz.dz && (s->no_fuse_dz < 0 || (!s->no_fuse_dz && batch > 1)) && groups == 1 && !cg1 && !s->plan_pair && !a.semi && !s->stamp_pcg) {
+        if (s->fz.dz && (s->no_fuse_dz < 0 || (!s->no_fuse_dz && batch > 1)) && groups == 1 && !cg1 && s->plan_pair != 1 && !a.semi && !s->stamp_pcg) {
             a.dz_Ginv = s->fz.Ginv; a.dz_Cd = s->fz.Cd; a.dz_g = s->fz.g; a.dz = s->fz.dz; a.C = s->d.C;
             s->dz_fused = 1;
         }

@@ -1093,6 +1093,66 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         dL[(size_t)j * S + r0] = lam[0];
         if (two) dL[(size_t)j * S + r0 + 1] = lam[1];
     }
+    // ---- dz back-substitution in the same launch (batches: one workgroup per system).  Formulas and accumulation order of
+    // dz_kernel (gato_assembly.hip; gato_schur.cuh:758-867, D2 fixed), row by row: bit-identical results.
+    if (a.dz != nullptr) {
+        const int Cn = a.C, n = S + Cn, k = j, nrow = two ? 2 : 1;
+        const size_t gs = (size_t)(S * S + Cn * Cn), cs = (size_t)(S * S + S * Cn), Nn = (size_t)n * K - Cn;
+        const T *__restrict__ Gi = static_cast<const T *>(a.dz_Ginv) + sys * (gs * K - (size_t)Cn * Cn);
+        const T *__restrict__ Cdn = static_cast<const T *>(a.dz_Cd) + sys * (cs * (K - 1));
+        const T *__restrict__ gv = static_cast<const T *>(a.dz_g) + sys * Nn;
+        T *__restrict__ dzo = static_cast<T *>(a.dz) + sys * Nn;
+        const bool last = k == K - 1;
+        __syncthreads();                                                         // every wave has left the loop: the windows are free
+        put(xs[0], lam);                                                         // lambda window
+        __syncthreads();
+        T tx[2] = {0, 0}, tu[2] = {0, 0};
+        if (active) {
+            for (int q = 0; q < nrow; ++q) {
+                const int rr = r0 + q;
+                if (!last) {
+                    const T *__restrict__ A = Cdn + (size_t)k * cs;
+                    const T *lp = &xs[0][(j + 2) * SP];                          // lambda_{k+1}
+                    T res = (T)0;
+#pragma unroll
+                    for (int t = 0; t < S; ++t) res = gato::fmaT(A[rr * S + t], lp[t], res);          // A_k^T lambda_{k+1}   :833-838
+                    tx[q] = gv[(size_t)k * n + rr] - (lam[q] + res);                                  // :841-852
+                    if (rr < Cn) {
+                        const T *__restrict__ B = A + S * S;
+                        T rb = (T)0;
+#pragma unroll
+                        for (int t = 0; t < S; ++t) rb = gato::fmaT(B[rr * S + t], lp[t], rb);        // B_k^T lambda_{k+1}   :784-789
+                        tu[q] = gv[(size_t)k * n + S + rr] - rb;                                      // :792-796
+                    }
+                } else tx[q] = gv[(size_t)k * n + rr] - lam[q];                                       // last state row (D2)
+                xs[1][(j + 1) * SP + rr] = tx[q];
+            }
+        }
+        __syncthreads();                                                         // lambda_{k+1} has been read everywhere
+        if (active && !last) {
+            for (int q = 0; q < nrow; ++q)
+                if (r0 + q < Cn) xs[0][(j + 1) * SP + r0 + q] = tu[q];
+        }
+        __syncthreads();
+        if (active) {
+            const T *__restrict__ Qi = Gi + (size_t)k * gs;
+            const T *tv = &xs[1][(j + 1) * SP];
+            for (int q = 0; q < nrow; ++q) {
+                const int rr = r0 + q;
+                T res = (T)0;
+#pragma unroll
+                for (int cc = 0; cc < S; ++cc) res = gato::fmaT(Qi[rr + cc * S], tv[cc], res);        // Q_k^-1 (...)         :856-865
+                dzo[(size_t)k * n + rr] = res;
+                if (!last && rr < Cn) {
+                    const T *__restrict__ Ri = Qi + S * S;
+                    const T *uv = &xs[0][(j + 1) * SP];
+                    T ru = (T)0;
+                    for (int cc = 0; cc < Cn; ++cc) ru = gato::fmaT(Ri[rr + cc * Cn], uv[cc], ru);    // R_k^-1 (...)         :799-808
+                    dzo[(size_t)k * n + S + rr] = ru;
+                }
+            }
+        }
+    }
     if (tid == 0) {
         a.iters[sys] = iters;
         if (a.final_eta && sys == 0) *a.final_eta = (double)eta_new;
@@ -1206,7 +1266,7 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
     if constexpr (sizeof(T) == 8 && MixedCfg<S>::wt > 0) {
         if (a.pair == 2) {
             constexpr int W2 = MixedCfg<S>::w2, WT = MixedCfg<S>::wt;
-            if (mr || a.groups != 1 || a.threads != 64 * WT || a.K * S > mixed_rows<S>() || a.stamps || a.dz) {
+            if (mr || a.groups != 1 || a.threads != 64 * WT || a.K * S > mixed_rows<S>() || a.stamps) {
                 set_error("pcg_resident(mixed): bad launch K=%d threads=%d", a.K, a.threads);
                 return GATO_EINVAL;
             }
