@@ -100,9 +100,10 @@ def latency_floor(sol, bufs, lam, production_us):
     out = {"us_per_iteration": floor, "products_us": spmv, "reductions_and_handoffs_us": red,
            "diagnostic_build_full_us": full, "loop_skeleton_us": nothing, "production_us_per_iteration": production_us,
            "frac_of_floor": floor / full if full > 0 else None,
-           "method": "live: diagnostic build of the same kernel (the production loop plus uniform branches on the timing-only "
-                     "switches; no cycle stamps), ablate = 3 (no products) / 4 (no reductions, no hand-offs) / 15 (loop "
-                     "skeleton); floor = products + reductions; frac_of_floor = floor / full, both in the diagnostic build"}
+           "method": "live: diagnostic builds of the same kernel with timing-only switches - ablate = 3 (no products) / 4 (no "
+                     "reductions, no hand-offs) / 15 (loop skeleton); floor = products + reductions; frac_of_floor = floor / "
+                     "full.  The one-workgroup fp64 kernel has the switches as compile-time variants (its 'full' IS the "
+                     "production kernel); pcg_resident_kernel has them as uniform run-time branches in a build of its own"}
     W = sol.get_option("last_groups")
     if W > 1:
         # what one all-to-all round of W workgroups costs with no arithmetic at all (tools/micro/pingpong.hip, MI355X)

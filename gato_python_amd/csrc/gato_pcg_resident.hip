@@ -940,7 +940,9 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
 // pairs, one 16-byte read per column - and the other waves own one row each with S and Pinv entirely in registers:
 // 8 x 42 window reads + W2 x 42 Pinv reads = 462 wave-reads per iteration.  Same recurrence, same per-row summation order
 // as every other kernel of the family (a row's 3S products are added left to right); block sums as in partials_store.
-template <int S, int W2, int WT, int DIAG = 0>
+// ABL: timing-only switches (bench.py's latency floor) as COMPILE-TIME constants - 3 no products, 4 no block sums, 15 loop
+// skeleton; with run-time switches this loop compiles 40 % slower than the production kernel, which is no yardstick.
+template <int S, int W2, int WT, int ABL = 0>
 __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 {
     typedef double T;
@@ -959,7 +961,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
     const int row0 = two ? 2 * tid : ROWS2 + (tid - L2);
     const int j = row0 / S, r0 = row0 - j * S;                                     // knot, (first) row inside it
     const bool active = row0 < K * S;
-    const int abl = DIAG ? a.ablate : 0;                                           // timing-only switches of the diagnostic build
+    constexpr int abl = ABL;
 
     const T *__restrict__ dS = static_cast<const T *>(a.S_bd) + sys * 3 * S * S * K;
     const T *__restrict__ dP = static_cast<const T *>(a.P_bd) + sys * 3 * S * S * K;
@@ -1271,8 +1273,12 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
                 return GATO_EINVAL;
             }
             if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-            if (a.diag == 2) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 2>), dim3(a.batch > 1 ? a.batch : 1), dim3(64 * WT), 0, st, a);
-            else hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 0>), dim3(a.batch > 1 ? a.batch : 1), dim3(64 * WT), 0, st, a);
+            const dim3 grid(a.batch > 1 ? a.batch : 1), block(64 * WT);
+            const int abl = a.diag == 2 ? a.ablate : 0;
+            if (abl == 3) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 3>), grid, block, 0, st, a);
+            else if (abl == 4) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 4>), grid, block, 0, st, a);
+            else if (abl == 15) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 15>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 0>), grid, block, 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;

@@ -45,7 +45,7 @@ if trace:
                 f.write(f'"{k[0]}",{k[1]},{k[2]},{len(g)},{sum(g) / len(g):.0f},{min(g)},{max(g)}\n')
 
 
-DIAG = re.compile(r"pcg_resident_kernel<\w+, \d+, \d+, \d+, (true|1|2),|pcg_single_f64m_kernel<\d+, \d+, \d+, [12]>")      # the diagnostic (STAMP) build: bench.py's latency-floor launches
+DIAG = re.compile(r"pcg_resident_kernel<\w+, \d+, \d+, \d+, (true|1|2),|pcg_single_f64m_kernel<\d+, \d+, \d+, [1-9]\d*>")      # the diagnostic (STAMP) build: bench.py's latency-floor launches
 
 
 def counter(kind):
