@@ -50,7 +50,7 @@ def test_bench_refuses_stale_traffic_entries():
     ok = dict(pcg_groups=1, pcg_threads=e["grid_threads"], dtype="f64", S=14)
     t, why = bench.committed_traffic("iiwa_14_7_k50_f64", ok)
     assert t == e["hbm_bytes_per_launch"] and why["git_blob"] and why["kernel"] == e["kernel"]
-    t, why = bench.committed_traffic("iiwa_14_7_k50_f64", dict(ok, pcg_threads=512))          # another geometry ran
+    t, why = bench.committed_traffic("iiwa_14_7_k50_f64", dict(ok, pcg_threads=e["grid_threads"] + 64))   # another geometry ran
     assert t is None and "stale" in why
     t, why = bench.committed_traffic("iiwa_14_7_k50_f64", dict(ok, dtype="f32"))              # another kernel family ran
     assert t is None and "stale" in why
