@@ -458,6 +458,36 @@ def test_random_resident_geometries():
         sol.close()
 
 
+def test_mixed_rows_kernel_every_size_it_serves():
+    """pcg_single_f64m_kernel (fp64, one workgroup, two rows per lane in three of its eight waves): every K it is
+    selected for at 14/7 - 37 (the first size beyond 512 register-resident rows) to 50 - against the oracle in fp64, with
+    and without a true warm start, and against the one-row-per-lane kernel on the same system."""
+    S, C = 14, 7
+    for K in range(37, 51):
+        s = synth.make_system(S, C, K, seed=100 + K)
+        Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, np.float64)
+        Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+        Pb = co.form_ss(Sb, Pb, S, K)
+        lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, 1e-9, 300)
+        res = {}
+        for no_pair in (0, 1):
+            sol = make_solver(S, C, K, np.float64)
+            sol.set_option("no_pair", no_pair)
+            lam, it = sol.pcg(sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam), 1e-9, 300)
+            assert sol.get_option("last_pair") == (0 if no_pair else 2) and sol.get_option("last_groups") == 1
+            assert int(host(it)[0]) == it_o, (K, no_pair)
+            assert rel(host(lam), lam_o) < 1e-9, (K, no_pair)
+            res[no_pair] = host(lam).copy()
+            if not no_pair and K % 4 == 1:                      # true warm start: the numpy restatement with the same lambda0
+                sol.set_option("true_warm_start", 1)
+                l0 = lam_o * (1 + 1e-3 * np.cos(np.arange(S * K)))
+                lam_w, it_w = o.pcg(Sb, Pb, gam, S, K, 1e-9, 300, lam0=l0)
+                lam2, it2 = sol.pcg(sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam), 1e-9, 300, lam=sol.to_device(l0))
+                assert int(host(it2)[0]) == it_w < it_o and rel(host(lam2), lam_w) < 1e-9, (K, int(host(it2)[0]), it_w, it_o)
+            sol.close()
+        assert rel(res[0], res[1]) < 1e-10, K
+
+
 def test_c_host_example():
     """examples/solve_pendulum.c: the reference's test case from plain C over the C ABI (no Python in the path)."""
     import subprocess
