@@ -120,6 +120,22 @@ def replicas_leg(args, torch, dist, rank, local, world):
                          "algorithmic_bytes_per_launch": bytes_launch}}
 
 
+def first_working_kind(kinds, attempt):
+    """The mirrors of the in-kernel transport in each memory kind the library knows, in turn (uncached device memory, then
+    fine-grained, then plain hipMalloc; GATO_XMEM pins one): attempt(kind) -> (cluster, "") when every rank could export
+    and map the mirrors AND the first solve came back complete on every rank, else (None, reason).  Returns the first
+    cluster that works (or None) and what was tried before it.  A rejection for size ("do not fit") ends the search."""
+    tried = []
+    for kind in kinds:
+        c, err = attempt(kind)
+        if c is not None:
+            return c, "; ".join(tried)[:300]
+        tried.append(f"{kind}: {err}"[:120])
+        if "do not fit" in err:
+            break
+    return None, "; ".join(tried)[:300]
+
+
 def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
     from . import synth
     from .dist import (ClusterPCG, ClusterUnavailable, HipShardBackend, ShardedPCG, _all_ranks_ok, allreduce_sum_, assemble_shard,
@@ -134,12 +150,6 @@ def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
     dev = f"cuda:{local}"
     want = os.environ.get("GATO_SHARD_TRANSPORT", "xgmi")
     transport, why, cl = "rccl", "", None
-    if want == "xgmi":
-        try:
-            cl = ClusterPCG(sol, rank, world)
-            transport = "xgmi"
-        except ClusterUnavailable as e:
-            why = f"mirrors unavailable: {e}"[:200]
 
     def assemble():
         Gd, Cd = sol.convert(*d[:6], sysm.rho)
@@ -168,20 +178,42 @@ def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
         lam, iters = ShardedPCG(be).solve(MAX_ITERS)
         return lam, sol.compute_dz(Gi, Cd, d[6], lam), iters
 
-    if transport == "xgmi":                               # first solve decides: a time-out anywhere sends every rank to RCCL
-        ok = True
-        try:
-            _, _, it0 = step_xgmi()
-            torch.cuda.synchronize()
-            ok = int(it0.cpu()[0]) == MAX_ITERS
+    if want == "xgmi":
+        def attempt(kind):
+            """One memory kind: (cluster or None, reason it was rejected).  Every decision inside is an AND over the ranks."""
+            nonlocal cl
+            os.environ["GATO_XMEM"] = kind
             try:
-                sol.check_status()
-            except Exception:     # noqa: BLE001
-                ok = False
-        except Exception as e:    # noqa: BLE001
-            ok, why = False, f"{type(e).__name__}: {e}"[:200]
-        if not _all_ranks_ok(ok):
-            transport, why = "rccl", why or "the first in-kernel exchange timed out on some rank"
+                cl = ClusterPCG(sol, rank, world)
+            except ClusterUnavailable as e:
+                cl = None
+                return None, f"mirrors unavailable: {e}"
+            ok, err = True, ""
+            try:
+                _, _, it0 = step_xgmi()
+                torch.cuda.synchronize()
+                ok = int(it0.cpu()[0]) == MAX_ITERS
+                try:
+                    sol.check_status()
+                except Exception:     # noqa: BLE001
+                    ok = False
+                if not ok:
+                    err = "the first in-kernel exchange timed out"
+            except Exception as e:    # noqa: BLE001
+                ok, err = False, f"{type(e).__name__}: {e}"
+            if _all_ranks_ok(ok):
+                return cl, ""
+            cl.close()
+            cl = None
+            xb.clear()
+            return None, err or "the first in-kernel exchange timed out on another rank"
+
+        pinned = os.environ.get("GATO_XMEM")
+        cl, why = first_working_kind([pinned] if pinned else ["uncached", "finegrained", "plain"], attempt)
+        if not pinned:
+            os.environ.pop("GATO_XMEM", None)
+        if cl is not None:
+            transport = "xgmi"
     step = step_xgmi if transport == "xgmi" else step_rccl
     el = _timed(lambda: step(), steps, warmup, torch, dist)
     lam, dz, iters = step()

@@ -89,3 +89,24 @@ def test_scipy_secondary_baseline_runs_the_same_iteration():
         return sp.bmat(blocks, format="csr")
     x, _ = spl.cg(bd(out["S"]), -out["gamma"], rtol=0.0, atol=0.0, maxiter=15, M=bd(out["Pinv"]))
     assert np.abs(x - out["lam"]).max() / np.abs(out["lam"]).max() < 1e-8
+
+
+def test_transport_search_over_mirror_memory_kinds():
+    """dist_bench.first_working_kind: the in-kernel transport is tried with the mirrors in each memory kind in turn; the
+    first kind in which every rank could map the mirrors and finish a solve is taken, a rejection for size ends the
+    search, and what was tried is kept for the bench line."""
+    from gato_python_amd.dist_bench import first_working_kind
+    calls = []
+
+    def attempt(kind):
+        calls.append(kind)
+        return ("cluster", "") if kind == "finegrained" else (None, "mirrors unavailable: connect: hipIpcOpenMemHandle")
+
+    c, why = first_working_kind(["uncached", "finegrained", "plain"], attempt)
+    assert c == "cluster" and calls == ["uncached", "finegrained"] and why.startswith("uncached: mirrors unavailable")
+    calls.clear()
+    c, why = first_working_kind(["uncached", "finegrained", "plain"], lambda k: (calls.append(k), (None, "the first in-kernel exchange timed out"))[1])
+    assert c is None and calls == ["uncached", "finegrained", "plain"] and why.count("timed out") == 3
+    calls.clear()
+    c, why = first_working_kind(["uncached", "finegrained"], lambda k: (calls.append(k), (None, "mirrors unavailable: 9 knots over 2 ranks do not fit one launch"))[1])
+    assert c is None and calls == ["uncached"]
