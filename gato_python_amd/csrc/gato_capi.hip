@@ -123,8 +123,11 @@ struct gato_solver {
     char *pin;            // pinned host staging (inputs, then iters | lambda | dz)
     size_t pin_bytes;
     int last_groups, last_threads, last_mode, last_variant, last_semi;
-    int time_pcg, stamp_pcg, ablate, no_single_lds, true_warm_start, no_pair, plan_pair, pcg_variant, xcd_pack;
+    int time_pcg, stamp_pcg, ablate, xcd_sel, no_single_lds, true_warm_start, no_pair, plan_pair, pcg_variant, xcd_pack;
     hipEvent_t ev_pcg0, ev_pcg1;
+    hipEvent_t ev_cal0, ev_cal1;         // XCD calibration of the one-XCD launches
+    long long xcd_cal_key;              // geometry the choice below was measured for (0 = none yet)
+    int xcd_cal_best, last_xcd_sel;
     // knot-sharded PCG state (gato_shard_pcg_*)
     struct {
         int rank, nranks, k0, k1, grid, max_iters;
@@ -350,6 +353,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     ops->pcg_plan(&s->plan);
     s->pcg_mode = GATO_PCG_AUTO;
     s->xcd_pack = -1;
+    s->xcd_sel = -1;
     s->pcg_semi = -1;
     s->timeout_ms = 2000;
     s->cluster_flat = 1;
@@ -402,6 +406,8 @@ extern "C" int gato_solver_destroy(gato_solver *s)
     gato_cluster_destroy(s);
     if (s->ev_pcg0) (void)hipEventDestroy(s->ev_pcg0);
     if (s->ev_pcg1) (void)hipEventDestroy(s->ev_pcg1);
+    if (s->ev_cal0) (void)hipEventDestroy(s->ev_cal0);
+    if (s->ev_cal1) (void)hipEventDestroy(s->ev_cal1);
     for (int i = 0; i < 4; ++i)
         if (s->ev_stage[i]) (void)hipEventDestroy(s->ev_stage[i]);
     if (s->arena) (void)hipFree(s->arena);
@@ -445,6 +451,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "pcg_variant")) s->pcg_variant = value;
     else if (!strcmp(name, "record_eta")) s->record_eta = value;
     else if (!strcmp(name, "xcd_pack")) s->xcd_pack = value;
+    else if (!strcmp(name, "xcd_sel")) s->xcd_sel = value < 0 ? -1 : (value & 7);
     else if (!strcmp(name, "true_warm_start")) s->true_warm_start = value;
     else if (!strcmp(name, "timeout_ms")) s->timeout_ms = value > 0 ? value : 2000;
     else if (!strcmp(name, "max_workgroups")) s->max_workgroups = value;
@@ -504,6 +511,7 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "last_threads")) *value = s->last_threads;
     else if (!strcmp(name, "last_mode")) *value = s->last_mode;
     else if (!strcmp(name, "last_pair")) *value = s->plan_pair;
+    else if (!strcmp(name, "last_xcd_sel")) *value = s->last_xcd_sel;
     else if (!strcmp(name, "last_variant")) *value = s->last_variant;
     else if (!strcmp(name, "asm_mode")) *value = s->asm_mode;
     else if (!strcmp(name, "last_asm_fused")) *value = s->last_asm_fused;
@@ -678,6 +686,56 @@ static int plan_cg1(gato_solver *s, int *groups, int *threads, int *kpw)
     return 1;
 }
 
+// One-XCD launches (xcd_pack): the hand-off granules live in one place in memory and the eight XCDs are not equally far
+// from it - measured 3.00 (best XCD) to 3.27 us (worst) per iteration at 14/7/512 f32, 3.10 to 3.37 at 14/7/1024, the
+// order depending on where this solver's hand-off area happened to land, stable for the life of the solver
+// (tools/xcd_sel_test.py).  So the first packed launch of a geometry is preceded by two rounds of eight short trial
+// launches (16 iterations each, the second round timed with HIP events; ~1 ms in all, host-blocking) and the fastest XCD
+// is kept.  The trials write the caller's output buffers, which the real launch then overwrites; a true warm start (the
+// output is also the input) and a stream that is being captured skip the calibration and take XCD 0.
+static int calibrate_xcd(gato_solver *s, const PcgLaunch &a0, bool cg1, hipStream_t st, int *best)
+{
+    *best = 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return GATO_OK; }
+    if (cap != hipStreamCaptureStatusNone || a0.lambda0 || a0.max_iters < 4) return GATO_OK;
+    if (!s->ev_cal0) {
+        GATO_HIP_CHECK(hipEventCreate(&s->ev_cal0));
+        GATO_HIP_CHECK(hipEventCreate(&s->ev_cal1));
+    }
+    PcgLaunch t = a0;
+    t.max_iters = a0.max_iters < 16 ? a0.max_iters : 16;
+    t.exit_tol = 0.0;
+    t.eta_hist = nullptr;
+    t.dz = nullptr;
+    t.stamps = nullptr; t.diag = 0; t.ablate = 0;
+    t.ev_start = s->ev_cal0; t.ev_stop = s->ev_cal1;
+    const unsigned need = 2u * (unsigned)t.max_iters + 8u;
+    if (s->pcg_epoch > 0xFFFFFFFFu - 17u * need - 64u) return GATO_OK;      // not worth a wrap of the epoch counter
+    float best_ms = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int sel = 0; sel < 8; ++sel) {
+            t.xcd_sel = sel;
+            t.epoch0 = s->pcg_epoch;
+            s->pcg_epoch += need;
+            if (++s->pcg_launch_id <= 0) s->pcg_launch_id = 1;
+            t.launch_id = s->pcg_launch_id;
+            int rc;
+            if ((rc = gate_before(s->device, s->num_cus, s->num_cus, st))) return rc;
+            rc = cg1 ? s->ops->pcg_cg1(t, st) : s->ops->pcg_resident(t, st);
+            if (rc == GATO_OK) rc = gate_after(s->device, s->num_cus, st);
+            if (rc) return rc;
+            GATO_HIP_CHECK(hipEventSynchronize(s->ev_cal1));
+            if (pass == 1) {
+                float ms = 0.f;
+                GATO_HIP_CHECK(hipEventElapsedTime(&ms, s->ev_cal0, s->ev_cal1));
+                if (sel == 0 || ms < best_ms) { best_ms = ms; *best = sel; }
+            }
+        }
+    }
+    return GATO_OK;
+}
+
 static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
                    double exit_tol, int max_iters, int *d_iters, int batch, hipStream_t st)
 {
@@ -712,6 +770,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
             else a.xcd_pack = (s->xcd_pack >= need && s->xcd_pack < 8) ? s->xcd_pack : 0;
         }
         if (a.semi) a.xcd_pack = 0;
+        a.xcd_sel = s->xcd_sel;
         if (a.xcd_pack > 0 && groups > s->num_cus / 8) a.xcd_pack = 0;     // an XCD with fewer CUs than workgroups (CU mask): plain grid
         a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
         a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
@@ -751,6 +810,25 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         const bool gated = batch == 1 && groups > 1;
         const int need_cus = a.xcd_pack > 0 ? s->num_cus : groups;
         int rc;
+        // one-XCD launches: which of the eight XCDs hosts them (option xcd_sel: -1 = measured once per geometry, 0..7 fixed)
+        s->last_xcd_sel = -1;
+        if (a.xcd_pack > 0) {
+            if (s->xcd_sel >= 0) a.xcd_sel = s->xcd_sel;
+            else {
+                const long long key = ((long long)groups << 32) | ((long long)threads << 8) | (cg1 ? 2 : 0) | (s->esz == 8 ? 1 : 0) | 4;
+                if (s->xcd_cal_key != key) {
+                    if ((rc = calibrate_xcd(s, a, cg1, st, &s->xcd_cal_best))) return rc;
+                    s->xcd_cal_key = key;
+                    // the trials drew launch ids and epochs of their own: this launch follows them
+                    a.epoch0 = s->pcg_epoch;
+                    s->pcg_epoch += need;
+                    if (++s->pcg_launch_id <= 0) s->pcg_launch_id = 1;
+                    a.launch_id = s->pcg_launch_id;
+                }
+                a.xcd_sel = s->xcd_cal_best;
+            }
+            s->last_xcd_sel = a.xcd_sel;
+        }
         if (gated && (rc = gate_before(s->device, s->num_cus, need_cus, st))) return rc;
         rc = cg1 ? s->ops->pcg_cg1(a, st) : a.semi == 3 ? s->ops->pcg_dma(a, st) : s->ops->pcg_resident(a, st);
         if (rc == GATO_OK && gated) rc = gate_after(s->device, need_cus, st);

@@ -41,9 +41,10 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
     const bool batched = a.batch > 1;
     // xcd_pack: see pcg_resident_kernel (placement hint: the working groups share X XCDs)
     const int X = a.xcd_pack;
-    if (X > 0 && (int)(blockIdx.x & 7) >= X) return;
+    const int xres = X > 0 ? (int)((blockIdx.x - (unsigned)a.xcd_sel) & 7) : 0;      // a.xcd_sel: which XCD(s) of the eight host the working blocks
+    if (X > 0 && xres >= X) return;
     const int per_x = X > 0 ? (int)(gridDim.x >> 3) : 0;
-    const int wg = batched ? 0 : (X > 0 ? (int)(blockIdx.x & 7) * per_x + (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+    const int wg = batched ? 0 : (X > 0 ? xres * per_x + (int)(blockIdx.x >> 3) : (int)blockIdx.x);
     const int W = batched ? 1 : (X > 0 ? a.groups : (int)gridDim.x);
     if (X > 0 && wg >= W) return;
     const size_t sys = batched ? blockIdx.x : 0;

@@ -84,6 +84,8 @@ void *gato_solver_buffer(gato_solver *s, int which);
  * recurrence; 1 = opt-in single-reduction Chronopoulos-Gear recurrence of the resident kernel: one inter-workgroup
  * hand-off per iteration instead of two, same solution to solver tolerance, different rounding), xcd_pack (-1 auto:
  * launches of up to 32 workgroups are placed on one XCD - a placement hint, never needed for correctness; 0 off),
+ * xcd_sel (which of the eight XCDs hosts such a launch: -1 = measured once per solver and geometry with a millisecond of
+ * trial launches before the first one, 0..7 fixed; read-only last_xcd_sel),
  * asm_mode (whole-solve entries: 0 = auto - convert + Schur + stair as ONE fused launch when K*B <= 2 x CUs, the
  * stage kernels otherwise; 1 = stage kernels; 2 = fused; both give bit-identical buffers), pcg_semi (-1 = auto: K
  * beyond the register file runs as one persistent launch - semi-resident, or with the block rows streamed through an

@@ -488,6 +488,34 @@ def test_mixed_rows_kernel_every_size_it_serves():
         assert rel(res[0], res[1]) < 1e-10, K
 
 
+def test_one_xcd_placement_is_a_hint_only():
+    """Launches of up to 32 workgroups are placed on ONE XCD (xcd_pack), and which of the eight hosts them is measured once
+    per solver and geometry (xcd_sel = -1) or fixed by option.  Whatever the placement, the bits are the same."""
+    S, C, K = 14, 7, 512
+    s = synth.make_system(S, C, K, seed=5)
+    ref = None
+    for opts in ({}, dict(xcd_sel=5), dict(xcd_sel=2), dict(xcd_pack=0)):
+        sol = make_solver(S, C, K, np.float32)
+        for k, v in opts.items():
+            sol.set_option(k, v)
+        dev = sol.upload_system(s)
+        lam, dz = sol.new(S * K), sol.new(sol.N)
+        for _ in range(2):                                   # the first call of a solver calibrates, the second does not
+            sol.linsys(*dev, 1e-5, 60, s.rho, lam, dz)
+            sol.check_status()
+        sel = sol.get_option("last_xcd_sel")
+        if "xcd_sel" in opts:
+            assert sel == opts["xcd_sel"]
+        elif opts.get("xcd_pack") == 0:
+            assert sel == -1
+        else:
+            assert 0 <= sel <= 7
+        if ref is None:
+            ref = (host(lam).copy(), host(dz).copy())
+        assert np.array_equal(host(lam), ref[0]) and np.array_equal(host(dz), ref[1]), opts
+        sol.close()
+
+
 def test_c_host_example():
     """examples/solve_pendulum.c: the reference's test case from plain C over the C ABI (no Python in the path)."""
     import subprocess
