@@ -37,6 +37,17 @@ if trace:
     with open(os.path.join(out, f"{tag}_pcg_launches.csv"), "w") as f:
         f.write("kernel,grid_threads,workgroup_threads,launches,avg_ns,min_ns,max_ns\n")
         for k, v in sorted(launch.items()):
+            # one-XCD launches (8x oversubscribed grid of the plain resident / single-reduction kernels): the first launch of a
+            # solver is preceded by 16 short calibration launches (16 iterations each, gato_capi.hip: calibrate_xcd) - listed apart
+            trials = []
+            packed = re.match(r"pcg_resident_kernel<\w+, \d+, \d+, 0, 0, 0, false, false>|pcg_cg1_kernel<", k[0]) and k[1] >= 16 * k[2]
+            if packed and len(v) > 16 and max(v) > 3 * min(v):
+                cut = max(v) / 3
+                short_ = [x for x in v if x < cut]
+                if short_ and len(short_) % 16 == 0:
+                    trials, v = short_, [x for x in v if x >= cut]
+            if trials:
+                f.write(f'"{k[0]} [XCD calibration trials, 16 iterations]",{k[1]},{k[2]},{len(trials)},{sum(trials) / len(trials):.0f},{min(trials)},{max(trials)}\n')
             groups = [v]
             if max(v) > 1.6 * min(v) and ", 16, false" in k[0]:      # two bench workloads on one (kernel, grid): split by duration
                 cut = (max(v) + min(v)) / 2
