@@ -693,9 +693,10 @@ static int plan_cg1(gato_solver *s, int *groups, int *threads, int *kpw)
 // launches (16 iterations each, the second round timed with HIP events; ~1 ms in all, host-blocking) and the fastest XCD
 // is kept.  The trials write the caller's output buffers, which the real launch then overwrites; a true warm start (the
 // output is also the input) and a stream that is being captured skip the calibration and take XCD 0.
-static int calibrate_xcd(gato_solver *s, const PcgLaunch &a0, bool cg1, hipStream_t st, int *best)
+static int calibrate_xcd(gato_solver *s, const PcgLaunch &a0, bool cg1, hipStream_t st, int *best, bool *measured)
 {
     *best = 0;
+    *measured = false;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return GATO_OK; }
     if (cap != hipStreamCaptureStatusNone || a0.lambda0 || a0.max_iters < 4) return GATO_OK;
@@ -733,6 +734,7 @@ static int calibrate_xcd(gato_solver *s, const PcgLaunch &a0, bool cg1, hipStrea
             }
         }
     }
+    *measured = true;
     return GATO_OK;
 }
 
@@ -817,8 +819,9 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
             else {
                 const long long key = ((long long)groups << 32) | ((long long)threads << 8) | (cg1 ? 2 : 0) | (s->esz == 8 ? 1 : 0) | 4;
                 if (s->xcd_cal_key != key) {
-                    if ((rc = calibrate_xcd(s, a, cg1, st, &s->xcd_cal_best))) return rc;
-                    s->xcd_cal_key = key;
+                    bool measured = false;
+                    if ((rc = calibrate_xcd(s, a, cg1, st, &s->xcd_cal_best, &measured))) return rc;
+                    s->xcd_cal_key = measured ? key : 0;          // skipped (warm start, capture, very short solve): next call tries again
                     // the trials drew launch ids and epochs of their own: this launch follows them
                     a.epoch0 = s->pcg_epoch;
                     s->pcg_epoch += need;
