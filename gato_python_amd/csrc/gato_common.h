@@ -93,13 +93,14 @@ __device__ __forceinline__ T row_sums_dpp(T v)
     v += dpp_mov<0x140, 0xf, true>(v);
     return v;
 }
-template <typename T>
+// N: how many of the lanes 0..15 can hold a value (the others are zero): 8 values need three steps, 4 need two
+template <typename T, int N = 16>
 __device__ __forceinline__ T row0_sum_dpp(T v)
 {
     v += dpp_mov<0xB1, 0xf, true>(v);
     v += dpp_mov<0x4E, 0xf, true>(v);
-    v += dpp_mov<0x141, 0xf, true>(v);
-    v += dpp_mov<0x140, 0xf, true>(v);
+    if constexpr (N > 4) v += dpp_mov<0x141, 0xf, true>(v);
+    if constexpr (N > 8) v += dpp_mov<0x140, 0xf, true>(v);
     return lane0(v);
 }
 template <typename T>

@@ -31,7 +31,7 @@ __device__ __forceinline__ void partials_store(T *wp, int wave, int lane, T prod
     const T rs = row_sums_dpp(prod);
     if ((lane & 15) == 0) wp[4 * wave + (lane >> 4)] = rs;
 }
-template <typename T>
+template <typename T, int MAXW = 16>
 __device__ __forceinline__ T partials_total(const T *wp, int nwaves, int lane)
 {
     typedef T __attribute__((ext_vector_type(4))) V4;
@@ -40,7 +40,7 @@ __device__ __forceinline__ T partials_total(const T *wp, int nwaves, int lane)
         const V4 q = *reinterpret_cast<const V4 *>(wp + 4 * lane);
         v = (q[0] + q[1]) + (q[2] + q[3]);
     }
-    return row0_sum_dpp(v);
+    return row0_sum_dpp<T, MAXW>(v);            // MAXW: compile-time bound of nwaves (8 waves: one DPP step less)
 }
 
 // ---- granule transport -------------------------------------------------------------------

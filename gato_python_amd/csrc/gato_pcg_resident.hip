@@ -879,7 +879,7 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         float *wp = wpart[epoch & 1];
         partials_store(wp, wave, lane, prod);
         __syncthreads();
-        return partials_total(wp, nwaves, lane);
+        return partials_total<float, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
     };
     auto put = [&](float *buf, f32x2 v) {
         if (active) *reinterpret_cast<f32x2 *>(buf + (j + 1) * SP + r0) = v;
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         T *wp = wpart[epoch & 1];
         partials_store(wp, wave, lane, prod);
         __syncthreads();
-        return partials_total(wp, WT, lane);
+        return partials_total<T, (WT <= 8 ? 8 : 16)>(wp, WT, lane);
     };
     auto put = [&](T *buf, V2 v) {
         if (active) {
