@@ -376,11 +376,11 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             // one workgroup: every wave sums the per-wave partials itself (fixed order), no second barrier
             // (one LDS read per lane + a DPP sum: a serial loop over the partials would pay one LDS
             //  round trip per wave)
-            total = partials_total(wp, nwaves, lane);
+            total = partials_total<T, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
             return;
         }
         if (wave == 0) {
-            T tot = partials_total(wp, nwaves, lane);
+            T tot = partials_total<T, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
             bool fail = false;
             if (W > 1) {
                 if (lane == 0) Gr::store(mine, epoch, tot);
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 }
             }
             if (wave == 0) {
-                T tot = partials_total(wp, nwaves, lane);
+                T tot = partials_total<T, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
                 if (lane < R) XGr::store((gu64 *)s_xpeer[lane] + so, xepoch, tot);   // the partial goes into EVERY mirror
                 gu64 *pbase = fl + a.flat_off + (size_t)(xepoch & 1) * WT * slotG;
                 int ln = lane;                                 // re-derived at every hand-off (see allreduce_and_halo)
