@@ -99,18 +99,13 @@ def latency_floor(sol, bufs, lam, production_us):
     floor = spmv + red
     out = {"us_per_iteration": floor, "products_us": spmv, "reductions_and_handoffs_us": red,
            "diagnostic_build_full_us": full, "loop_skeleton_us": nothing, "production_us_per_iteration": production_us,
-           "frac_of_floor": floor / full if full > 0 else None,
-           "method": "live: diagnostic builds of the same kernel with timing-only switches - ablate = 3 (no products) / 4 (no "
-                     "reductions, no hand-offs) / 15 (loop skeleton); floor = products + reductions; frac_of_floor = floor / "
-                     "full.  The one-workgroup fp64 kernel has the switches as compile-time variants (its 'full' IS the "
-                     "production kernel); pcg_resident_kernel has them as uniform run-time branches in a build of its own"}
+           "frac_of_floor": floor / full if full > 0 else None}
     W = sol.get_option("last_groups")
     if W > 1:
         # what one all-to-all round of W workgroups costs with no arithmetic at all (tools/micro/pingpong.hip, MI355X)
         pp = 0.42 if W <= 2 else 0.59 if W <= 15 else 0.84 if W <= 32 else 1.07
         out["handoff_floor_us"] = pp
         out["us_per_iteration_with_handoff_floor"] = spmv + 2 * pp
-        out["handoff_floor_source"] = "tools/micro/pingpong.hip all-to-all round, one polling wave per workgroup: 0.42 (W=2) / 0.59 (W=15) / 0.84 (W=29) us on one XCD, 1.03-1.10 us chip-wide"
     return out
 
 
@@ -338,6 +333,157 @@ def annotate(r, name=None):
     return r
 
 
+NOTES = {
+    "latency_floor": "live: diagnostic builds of the same kernel with timing-only switches - ablate = 3 (no products) / 4 (no "
+                     "reductions, no hand-offs) / 15 (loop skeleton); floor = products + reductions; frac_of_floor = floor / "
+                     "full.  The one-workgroup fp64 kernel has the switches as compile-time variants (its 'full' IS the "
+                     "production kernel); pcg_resident_kernel has them as uniform run-time branches in a build of its own",
+    "handoff_floor": "tools/micro/pingpong.hip all-to-all round, one polling wave per workgroup: 0.42 (W=2) / 0.59 (W=15) / "
+                     "0.84 (W=29) us on one XCD, 1.03-1.10 us chip-wide",
+    "traffic": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile.sh + "
+               "tools/summarize_profile.py), 2*FETCH_SIZE + WRITE_SIZE per launch; refused when kernel family or grid differ from this run",
+    "regime": "register/LDS-resident launches read the matrices from HBM once per LAUNCH; an iteration is bound by its two "
+              "dependent block reductions (hand-offs for W > 1) and LDS operand reads (DESIGN.md 3.1); the HBM-bound run of "
+              "this path is sweep entry iiwa_14_7_k131072_f32",
+}
+LINE_LIMIT = 4096          # the driver keeps a tail of stdout: the LAST line must be the whole headline object
+
+
+def _clean(x, digits=6):
+    """Strict-JSON values: NaN / inf -> null, floats rounded to `digits` significant digits, numpy scalars -> Python."""
+    import math
+    if isinstance(x, dict):
+        return {str(k): _clean(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_clean(v, digits) for v in x]
+    if isinstance(x, (bool, type(None), str, int)):
+        return x
+    if isinstance(x, np.integer):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if not math.isfinite(x):
+            return None
+        return float(f"{x:.{digits}g}")
+    return str(x)
+
+
+def dumps_strict(obj, limit=None):
+    line = json.dumps(_clean(obj), allow_nan=False, separators=(",", ":"))
+    if limit is not None and len(line) >= limit:
+        raise ValueError(f"bench line is {len(line)} bytes, limit {limit}")
+    return line
+
+
+def roofline_object(res, traffic, traffic_src):
+    """The `roofline` object of a line: bound = the roofline that bounds the PATH (HBM: GEMV-shaped iteration); `limiter` =
+    what the measured launch actually sits on, from the ratio of measured HBM traffic to algorithmic bytes."""
+    alg = res["algorithmic_bytes_per_launch"]
+    ratio = (traffic / alg) if traffic else None
+    streams = (ratio is not None and ratio >= 0.7) or "streaming" in str(res.get("pcg_mode", ""))
+    lf = res.get("latency_floor")
+    ro = {"bound": "hbm", "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": traffic,
+          "traffic_over_algorithmic": ratio,
+          "limiter": "hbm" if streams else "latency (matrices register/LDS-resident: HBM read once per launch)",
+          "kernel": "pcg_" + str(res["pcg_mode"]), "launch_ms": res["pcg_launch_ms"],
+          "algorithmic_bytes_per_launch": alg, "pcg_only_iterations_per_s": res["pcg_iters_per_s"]}
+    if isinstance(traffic_src, dict):
+        ro["traffic_source"] = {"file": traffic_src.get("file"), "git_blob": (traffic_src.get("git_blob") or "")[:12],
+                                "kernel": str(traffic_src.get("kernel"))[:80], "grid_threads": traffic_src.get("grid_threads")}
+    else:
+        ro["traffic_source"] = str(traffic_src)[:120]
+    if lf:
+        ro["latency_floor"] = {k: lf[k] for k in ("us_per_iteration", "products_us", "reductions_and_handoffs_us",
+                                                   "production_us_per_iteration", "frac_of_floor", "handoff_floor_us",
+                                                   "us_per_iteration_with_handoff_floor") if k in lf}
+    return ro
+
+
+def headline(res, name, steps, warmup, traffic, traffic_src, cpu=None, sweep_file=None):
+    """The ONE line the driver parses (last line of stdout, < LINE_LIMIT bytes, strict JSON).  Everything verbose - the
+    sweep, the method notes - is printed on earlier lines and written to `sweep_file`."""
+    S, C, K, dt, cfg = WORKLOADS[name]
+    out = {
+        "metric": "PCG iterations/s", "value": res["iters_per_s"], "unit": "iterations/s",
+        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": res["ms_per_step"],
+        "timed_steps": res["timed_steps"],      # blocks of exactly `steps` steps, repeated until 0.25 s of timed work
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": res["dtype"], "data": "synthetic",
+        "config": {"workload": name, "baseline_config": cfg, "STATE_SIZE": S, "CONTROL_SIZE": C, "KNOT_POINTS": K,
+                   "max_iters": MAX_ITERS, "exit_tol": 0.0,
+                   "step": "convert + Schur/stair assembly + PCG(100 iterations) + dz, inputs resident in HBM",
+                   "pcg_kernel": res["pcg_mode"], "pcg_workgroups": res["pcg_groups"],
+                   "pcg_threads": res["pcg_threads"]},
+        "roofline": roofline_object(res, traffic, traffic_src),
+    }
+    if cpu is not None:
+        out["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cpu}
+        if "tried" in cpu:
+            out["cpu_baseline"]["tried"] = cpu["tried"]
+        sec = cpu.get("secondary")
+        if isinstance(sec, dict) and "value" in sec:
+            out["cpu_baseline"]["scipy_cg_value"] = sec["value"]
+    if sweep_file:
+        out["sweep_file"] = sweep_file
+    return out
+
+
+def sweep_summary(entry):
+    """One short record per sweep entry for the headline line (the full entries are earlier stdout lines + the sweep file)."""
+    r = {"us_per_iter": entry.get("pcg_us_per_iter"), "iters_per_s": entry.get("iters_per_s")}
+    if entry.get("roofline_frac") is not None:
+        r["hbm_frac"] = entry["roofline_frac"]
+    elif entry.get("achieved_gbs") is not None:
+        r["alg_gbs"] = entry["achieved_gbs"]
+    return r
+
+
+def run_sweep(args, torch, emit):
+    """The other single-GPU shapes; every finished entry goes to emit() at once (its own stdout line + the sweep file)."""
+    def aux(other, **kw):
+        r, _ = run_single(other, max(10, args.steps // 10), 3, torch, **kw)
+        return r
+    for other in ("iiwa_14_7_k50_f32", "iiwa_14_7_k512_f32", "iiwa_14_7_k4096_f32", "iiwa_14_7_k4096_f64",
+                  "s32_c16_k1024_f32"):
+        r, r2 = aux(other), aux(other)                 # auxiliary entries: best of two short runs
+        if r2["iters_per_s"] > r["iters_per_s"]:
+            r = r2
+        annotate(r)
+        if not args.no_cpu:
+            So, Co, Ko, dto, _ = WORKLOADS[other]
+            from gato_python_amd import synth as _synth
+            r["cpu_baseline"] = cpu_baseline(_synth.make_system(So, Co, Ko, seed=0), dto, budget_s=3.0)
+        emit(r)
+    # opt-in single-reduction variant (one hand-off per iteration; rounding differs from the reference recurrence)
+    for other in ("iiwa_14_7_k512_f32", "iiwa_14_7_k4096_f32", "s32_c16_k1024_f32"):
+        r = aux(other, variant=1)
+        annotate(r, other + "_single_reduction_variant")
+        r["workload"] += "_single_reduction_variant"
+        emit(r)
+    # SURVEY.md 8d run 3: the K=512 system through the STREAMING kernels (matrices re-read every iteration; they fit L2,
+    # so the PMC passes show how little of that reaches HBM) beside the register-resident entry above
+    r = aux("iiwa_14_7_k512_f32", pcg_mode=2)
+    annotate(r, "iiwa_14_7_k512_f32_streaming")
+    r["workload"] += "_streaming"
+    emit(r)
+    # batches of independent systems (SURVEY.md section 8f N1): throughput mode of the K=50 shape
+    emit(run_batched(14, 7, 50, np.float64, 512, 10, 2, torch))
+    emit(run_batched(14, 7, 50, np.float32, 512, 10, 2, torch))
+    r, _ = run_single("iiwa_14_7_k16384_f32", 5, 2, torch, pcg_reps=5)
+    emit(annotate(r))
+    # HBM-bound regime (matrices 1.2 GB): 20 iterations per solve keep the run short.  Auto = the persistent launch
+    # whose block rows stream through an LDS-DMA ring (gato_pcg_dma.hip: one workgroup per CU, all vectors in
+    # registers); beside it the semi-resident persistent launch (7 % of the block rows in registers, the rest re-read
+    # by plain loads every product) and the streaming kernels (two launches per iteration, LDS-DMA tiles).
+    for mode, semi, tag in ((None, None, ""), (None, 1, "_semi"), (2, None, "_streaming")):
+        r, _ = run_single("iiwa_14_7_k131072_f32", 3, 1, torch, pcg_mode=mode, pcg_reps=5, max_iters=20, pcg_semi=semi)
+        annotate(r, "iiwa_14_7_k131072_f32" + tag)
+        r["workload"] += tag
+        r["max_iters"] = 20
+        emit(r)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -347,6 +493,8 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pcg-mode", type=int, default=None)
+    ap.add_argument("--sweep-out", default=os.path.join("gpurun_out", "bench_sweep.json"),
+                    help="file that receives the sweep entries and the method notes (the last stdout line stays compact)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -375,76 +523,46 @@ def main():
     S, C, K, dt, cfg = WORKLOADS[name]
     res, sysm = run_single(name, args.steps, args.warmup, torch, args.pcg_mode, min_seconds=0.25)
     traffic, traffic_src = committed_traffic(name, res)
-    out = {
-        "metric": "PCG iterations/s", "value": res["iters_per_s"], "unit": "iterations/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
-        "timed_steps": res["timed_steps"],      # blocks of exactly `steps` steps, repeated until 0.25 s of timed work
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": res["dtype"], "data": "synthetic",
-        "config": {"workload": name, "baseline_config": cfg, "STATE_SIZE": S, "CONTROL_SIZE": C, "KNOT_POINTS": K,
-                   "max_iters": MAX_ITERS, "exit_tol": 0.0,
-                   "step": "convert + Schur/stair assembly + PCG(100 iterations) + dz, inputs resident in HBM",
-                   "pcg_kernel": res["pcg_mode"], "pcg_workgroups": res["pcg_groups"],
-                   "pcg_threads": res["pcg_threads"]},
-        "roofline": {"bound": "hbm", "achieved": res["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": res["achieved_gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "latency_floor": res["latency_floor"],
-                     "kernel": "pcg_" + str(res["pcg_mode"]), "launch_ms": res["pcg_launch_ms"],
-                     "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_launch"],
-                     "pcg_only_iterations_per_s": res["pcg_iters_per_s"],
-                     "regime": "matrices register/LDS-resident on one CU: the launch reads them from HBM once (traffic), "
-                               "an iteration is bound by its two dependent block reductions and LDS operand reads, not by "
-                               "HBM (DESIGN.md 3.1); the HBM-bound run of this path is sweep entry iiwa_14_7_k131072_f32"},
-    }
+    cpu = None
     if not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(sysm, dt)
+        cpu = cpu_baseline(sysm, dt)
         try:
-            out["cpu_baseline"]["secondary"] = scipy_cg_baseline(sysm, dt)
+            cpu["secondary"] = scipy_cg_baseline(sysm, dt)
         except Exception as ex:       # noqa: BLE001
-            out["cpu_baseline"]["secondary"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
-    if not args.no_sweep and args.workload is None:
-        sweep = []
-        for other in ("iiwa_14_7_k50_f32", "iiwa_14_7_k512_f32", "iiwa_14_7_k4096_f32", "iiwa_14_7_k4096_f64",
-                      "s32_c16_k1024_f32"):
-            r, _ = run_single(other, max(10, args.steps // 10), 3, torch)
-            r2, _ = run_single(other, max(10, args.steps // 10), 3, torch)      # auxiliary entries: best of two short runs
-            if r2["iters_per_s"] > r["iters_per_s"]:
-                r = r2
-            annotate(r)
-            if not args.no_cpu:
-                So, Co, Ko, dto, _ = WORKLOADS[other]
-                from gato_python_amd import synth as _synth
-                r["cpu_baseline"] = cpu_baseline(_synth.make_system(So, Co, Ko, seed=0), dto, budget_s=3.0)
-            sweep.append(r)
-        # opt-in single-reduction variant (one hand-off per iteration; rounding differs from the reference recurrence)
-        for other in ("iiwa_14_7_k512_f32", "iiwa_14_7_k4096_f32", "s32_c16_k1024_f32"):
-            r, _ = run_single(other, max(10, args.steps // 10), 3, torch, variant=1)
-            annotate(r, other + "_single_reduction_variant")
-            r["workload"] += "_single_reduction_variant"
-            sweep.append(r)
-        # SURVEY.md 8d run 3: the K=512 system through the STREAMING kernels (matrices re-read every iteration; they fit L2,
-        # so the PMC passes show how little of that reaches HBM) beside the register-resident entry above
-        r, _ = run_single("iiwa_14_7_k512_f32", max(10, args.steps // 10), 3, torch, pcg_mode=2)
-        annotate(r, "iiwa_14_7_k512_f32_streaming")
-        r["workload"] += "_streaming"
-        sweep.append(r)
-        # batches of independent systems: throughput mode of the K=50 shape
-        sweep.append(run_batched(14, 7, 50, np.float64, 512, 10, 2, torch))
-        sweep.append(run_batched(14, 7, 50, np.float32, 512, 10, 2, torch))
-        r, _ = run_single("iiwa_14_7_k16384_f32", 5, 2, torch, pcg_reps=5)
-        sweep.append(annotate(r))
-        # HBM-bound regime (matrices 1.2 GB): 20 iterations per solve keep the run short.  Auto = the persistent launch
-        # whose block rows stream through an LDS-DMA ring (gato_pcg_dma.hip: one workgroup per CU, all vectors in
-        # registers); beside it the semi-resident persistent launch (7 % of the block rows in registers, the rest re-read
-        # by plain loads every product) and the streaming kernels (two launches per iteration, LDS-DMA tiles).
-        for mode, semi, tag in ((None, None, ""), (None, 1, "_semi"), (2, None, "_streaming")):
-            r, _ = run_single("iiwa_14_7_k131072_f32", 3, 1, torch, pcg_mode=mode, pcg_reps=5, max_iters=20, pcg_semi=semi)
-            annotate(r, "iiwa_14_7_k131072_f32" + tag)
-            r["workload"] += tag
-            r["max_iters"] = 20
-            sweep.append(r)
-        out["sweep"] = sweep
-    print(json.dumps(out))
+            cpu["secondary"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+    sweep, sweep_err = [], None
+    do_sweep = not args.no_sweep and args.workload is None
+
+    def emit(entry):
+        sweep.append(entry)
+        print(dumps_strict({"sweep_entry": entry}), flush=True)          # an EARLIER stdout line, never the last one
+
+    if do_sweep:
+        try:
+            run_sweep(args, torch, emit)
+        except Exception as ex:       # noqa: BLE001  - the headline below must be printed whatever a sweep entry does
+            sweep_err = f"{type(ex).__name__}: {ex}"[:300]
+    sweep_file = None
+    if do_sweep:
+        try:
+            os.makedirs(os.path.dirname(args.sweep_out) or ".", exist_ok=True)
+            with open(args.sweep_out, "w") as f:
+                f.write(dumps_strict({"headline_workload": name, "headline": res, "cpu_baseline": cpu, "sweep": sweep,
+                                      "sweep_error": sweep_err, "notes": NOTES}))
+            sweep_file = args.sweep_out
+        except OSError:
+            pass
+    out = headline(res, name, args.steps, args.warmup, traffic, traffic_src, cpu, sweep_file)
+    if do_sweep:
+        out["sweep"] = {e["workload"]: sweep_summary(e) for e in sweep}
+        if sweep_err:
+            out["sweep_error"] = sweep_err[:160]
+    try:
+        line = dumps_strict(out, LINE_LIMIT)
+    except ValueError:                 # never lose the headline to its riders
+        out.pop("sweep", None)
+        line = dumps_strict(out, LINE_LIMIT)
+    print(line, flush=True)
 
 
 if __name__ == "__main__":

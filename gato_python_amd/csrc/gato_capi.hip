@@ -128,6 +128,9 @@ struct gato_solver {
     hipEvent_t ev_cal0, ev_cal1;         // XCD calibration of the one-XCD launches
     long long xcd_cal_key;              // geometry the choice below was measured for (0 = none yet)
     int xcd_cal_best, last_xcd_sel;
+    int tuning;                         // inside gato_solver_tune: pcg_one plans, runs the trials on scratch and returns
+    int *tune_iters, *tune_status;      // scratch words of the trial launches (never the caller's, never the sticky status)
+    double *tune_eta;
     // knot-sharded PCG state (gato_shard_pcg_*)
     struct {
         int rank, nranks, k0, k1, grid, max_iters;
@@ -315,6 +318,8 @@ extern "C" int gato_compute_dz(gato_solver *s, const void *d_Ginv_dense, const v
                                const void *d_lambda, void *d_dz, void *stream);
 extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
                         double exit_tol, int max_iters, int *d_iters, void *stream);
+extern "C" int gato_solver_tune(gato_solver *s, void *stream);
+extern "C" int gato_solver_destroy(gato_solver *s);
 
 extern "C" int gato_solver_create(int S, int C, int K, int dtype, int device, gato_solver **out)
 {
@@ -387,6 +392,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     s->status = (int *)(a + o_status);
     s->iters = B > 1 ? (int *)(a + o_its) : (int *)(a + o_status + 8);
     s->final_eta = (double *)(a + o_status + 16);
+    s->tune_status = (int *)(a + o_status + 32); s->tune_iters = (int *)(a + o_status + 40); s->tune_eta = (double *)(a + o_status + 48);
     s->G_dense = a + o_G; s->C_dense = a + o_C; s->Ginv = a + o_Gi;
     s->Sbd = a + o_S; s->Pbd = a + o_P; s->gamma = a + o_gam; s->lambda = a + o_lam; s->dz = a + o_dz;
     s->sw.vecs = a + o_vec;
@@ -395,6 +401,13 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     s->ghosts = a + o_gh;
     s->eta_hist = (double *)(a + o_hist);
     s->cl_tab = (unsigned long long **)(a + o_xtab);
+    // placement of the one-XCD launches of the default geometry: measured here, where the caller waits anyway
+    // (allocation, memset), never inside an enqueue-only entry.  GATO_NO_TUNE=1 skips it (XCD 0).
+    const char *nt = getenv("GATO_NO_TUNE");
+    if (!(nt && atoi(nt))) {
+        const int rc = gato_solver_tune(s, nullptr);
+        if (rc) { gato_solver_destroy(s); return rc; }
+    }
     *out = s;
     return GATO_OK;
 }
@@ -689,17 +702,19 @@ static int plan_cg1(gato_solver *s, int *groups, int *threads, int *kpw)
 // One-XCD launches (xcd_pack): the hand-off granules live in one place in memory and the eight XCDs are not equally far
 // from it - measured 3.00 (best XCD) to 3.27 us (worst) per iteration at 14/7/512 f32, 3.10 to 3.37 at 14/7/1024, the
 // order depending on where this solver's hand-off area happened to land, stable for the life of the solver
-// (tools/xcd_sel_test.py).  So the first packed launch of a geometry is preceded by two rounds of eight short trial
-// launches (16 iterations each, the second round timed with HIP events; ~1 ms in all, host-blocking) and the fastest XCD
-// is kept.  The trials write the caller's output buffers, which the real launch then overwrites; a true warm start (the
-// output is also the input) and a stream that is being captured skip the calibration and take XCD 0.
+// (tools/xcd_sel_test.py).  The hosting XCD of a geometry is therefore MEASURED: two rounds of eight short trial launches
+// (16 iterations each, the second round timed with HIP events; ~1 ms in all, host-blocking), the fastest XCD is kept.
+// This happens in gato_solver_tune() only - called by gato_solver_create for the geometry the solver's defaults plan,
+// and by the caller again after changing geometry options - on the solver's OWN buffers (work vectors as lambda, a
+// scratch iters / status / eta word): the enqueue-only entries (gato_pcg, gato_linsys_device, ...) never calibrate, never
+// wait on the host and never touch caller buffers for it; a geometry without a measurement runs on XCD 0.
 static int calibrate_xcd(gato_solver *s, const PcgLaunch &a0, bool cg1, hipStream_t st, int *best, bool *measured)
 {
     *best = 0;
     *measured = false;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return GATO_OK; }
-    if (cap != hipStreamCaptureStatusNone || a0.lambda0 || a0.max_iters < 4) return GATO_OK;
+    if (cap != hipStreamCaptureStatusNone || a0.max_iters < 4) return GATO_OK;
     if (!s->ev_cal0) {
         GATO_HIP_CHECK(hipEventCreate(&s->ev_cal0));
         GATO_HIP_CHECK(hipEventCreate(&s->ev_cal1));
@@ -709,10 +724,14 @@ static int calibrate_xcd(gato_solver *s, const PcgLaunch &a0, bool cg1, hipStrea
     t.exit_tol = 0.0;
     t.eta_hist = nullptr;
     t.dz = nullptr;
+    t.lambda0 = nullptr;
     t.stamps = nullptr; t.diag = 0; t.ablate = 0;
     t.ev_start = s->ev_cal0; t.ev_stop = s->ev_cal1;
     const unsigned need = 2u * (unsigned)t.max_iters + 8u;
-    if (s->pcg_epoch > 0xFFFFFFFFu - 17u * need - 64u) return GATO_OK;      // not worth a wrap of the epoch counter
+    if (s->pcg_epoch > 0xFFFFFFFFu - 17u * need - 64u) {                    // counter about to wrap: start over on zeroed granules
+        GATO_HIP_CHECK(hipMemsetAsync(s->slots, 0, s->slots_bytes, st));
+        s->pcg_epoch = 0;
+    }
     float best_ms = 0.f;
     for (int pass = 0; pass < 2; ++pass) {
         for (int sel = 0; sel < 8; ++sel) {
@@ -818,25 +837,33 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
             if (s->xcd_sel >= 0) a.xcd_sel = s->xcd_sel;
             else {
                 const long long key = ((long long)groups << 32) | ((long long)threads << 8) | (cg1 ? 2 : 0) | (s->esz == 8 ? 1 : 0) | 4;
-                if (s->xcd_cal_key != key) {
+                if (s->tuning) {
+                    // gato_solver_tune: the trial launches (scratch outputs, own events); no launch of the caller's follows
                     bool measured = false;
+                    a.iters = s->tune_iters; a.status = s->tune_status; a.final_eta = s->tune_eta;
                     if ((rc = calibrate_xcd(s, a, cg1, st, &s->xcd_cal_best, &measured))) return rc;
-                    s->xcd_cal_key = measured ? key : 0;          // skipped (warm start, capture, very short solve): next call tries again
-                    // the trials drew launch ids and epochs of their own: this launch follows them
-                    a.epoch0 = s->pcg_epoch;
-                    s->pcg_epoch += need;
-                    if (++s->pcg_launch_id <= 0) s->pcg_launch_id = 1;
-                    a.launch_id = s->pcg_launch_id;
+                    s->xcd_cal_key = measured ? key : 0;
+                    s->last_xcd_sel = measured ? s->xcd_cal_best : -1;
+                    return GATO_OK;
                 }
-                a.xcd_sel = s->xcd_cal_best;
+                a.xcd_sel = s->xcd_cal_key == key ? s->xcd_cal_best : 0;       // not measured for this geometry: XCD 0
             }
             s->last_xcd_sel = a.xcd_sel;
         }
-        if (gated && (rc = gate_before(s->device, s->num_cus, need_cus, st))) return rc;
+        if (s->tuning) return GATO_OK;                                       // nothing to measure for this geometry
+        bool capturing = false;
+        if (gated) {                // the gate queries and records events: not inside a stream capture (the graph's own
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;          // dependencies order its launches)
+            if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+            capturing = cap != hipStreamCaptureStatusNone;
+        }
+        const bool gate = gated && !capturing;
+        if (gate && (rc = gate_before(s->device, s->num_cus, need_cus, st))) return rc;
         rc = cg1 ? s->ops->pcg_cg1(a, st) : a.semi == 3 ? s->ops->pcg_dma(a, st) : s->ops->pcg_resident(a, st);
-        if (rc == GATO_OK && gated) rc = gate_after(s->device, need_cus, st);
+        if (rc == GATO_OK && gate) rc = gate_after(s->device, need_cus, st);
         return rc;
     }
+    if (s->tuning) return GATO_OK;
     s->last_stream = st;
     s->last_mode = GATO_PCG_STREAMING; s->last_groups = 0; s->last_threads = 0; s->last_semi = 0;
     s->dz_fused = 0;
@@ -869,6 +896,31 @@ extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, con
                          max_iters, its + b, 1, st);
         if (rc) return rc;
     }
+    return GATO_OK;
+}
+
+// Measures, for the geometry the solver's CURRENT options plan, which XCD should host a one-XCD launch (see above
+// calibrate_xcd).  Blocking (~1 ms: 16 short launches, each waited for); runs on `stream`, reads the solver's own S / Pinv /
+// gamma work buffers (whatever they hold: the launches run a fixed iteration count and their results are discarded) and
+// writes only solver-owned scratch.  A no-op for batches, cluster ranks and geometries that are not one-XCD launches.
+// gato_solver_create calls it once; call it again after changing pcg_threads / pcg_groups / pcg_variant / max_workgroups
+// / xcd_pack if those launches should keep the measured placement (unmeasured geometries run on XCD 0: a placement
+// hint only, results never depend on it).
+extern "C" int gato_solver_tune(gato_solver *s, void *stream)
+{
+    if (!s) { set_error("solver_tune: null solver"); return GATO_EINVAL; }
+    if (s->d.B != 1 || s->cl.on || s->xcd_sel >= 0 || s->pcg_mode == GATO_PCG_STREAMING) return GATO_OK;
+    GATO_HIP_CHECK(hipSetDevice(s->device));
+    const int saved_tws = s->true_warm_start, saved_stamp = s->stamp_pcg;
+    hipStream_t saved_stream = s->last_stream;
+    s->true_warm_start = 0; s->stamp_pcg = 0;
+    s->tuning = 1;
+    const int rc = pcg_one(s, s->Sbd, s->Pbd, s->gamma, s->sw.vecs, 0.0, 16, s->tune_iters, 1, (hipStream_t)stream);
+    s->tuning = 0;
+    s->true_warm_start = saved_tws; s->stamp_pcg = saved_stamp;
+    s->last_stream = saved_stream;
+    if (rc) return rc;
+    GATO_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return GATO_OK;
 }
 

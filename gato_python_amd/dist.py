@@ -16,12 +16,15 @@ host reads device data inside the loop: kernels and collectives are only enqueue
 ShardedPCG is the orchestration; the arithmetic lives behind a backend object (HipShardBackend: the HIP
 kernels through the C ABI, gato_shard_pcg_* in include/gato_hip.h).
 
-ClusterPCG is the xGMI-native transport and the default of linsys_solve_sharded: ONE persistent launch per rank
+ClusterPCG is the xGMI-native transport (whole solve: linsys_solve_cluster; linsys_solve_auto takes it when it can be
+connected and falls back to linsys_solve_sharded otherwise): ONE persistent launch per rank
 per solve, in which the exchange above happens inside the kernel - every rank stores its {epoch, payload}
 granules straight into the peers' IPC-mapped mirrors (system-scope stores over xGMI) and polls only its own
 (gato_cluster_* in include/gato_hip.h, pcg_resident_kernel<..., MR>).  torch.distributed carries the 64-byte
 IPC handles once and the barrier after connecting; nothing of it runs inside the solve.  The all-gather
-schedule above (two launches + two RCCL collectives per iteration) stays as the portable fallback.
+schedule above (two launches + two RCCL collectives per iteration, linsys_solve_sharded) stays as the portable
+fallback.  connect_cluster() is the one place that decides: mirrors in each memory kind in turn, a probe solve, every
+decision an AND over the ranks, ClusterUnavailable on all ranks together when nothing works.
 """
 from __future__ import annotations
 
@@ -368,21 +371,114 @@ def dz_shard(sol, d, bufs, lam, dz, k0, k1):
     return dz
 
 
-def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None, state=None):
-    """Whole solve with the PCG sharded over the ranks of `group` through the in-kernel xGMI hand-off.  Assembly is
-    replicated (one-off O(K), needs no exchange), each rank's launch solves its knot range, lambda is assembled by one
-    sum-all-reduce of the disjoint slices per solve (outside the iteration loop), dz is computed redundantly.
+MIRROR_KINDS = ("uncached", "finegrained", "plain")
+
+
+def first_working_kind(kinds, attempt):
+    """The mirrors of the in-kernel transport in each memory kind the library knows, in turn (uncached device memory, then
+    fine-grained, then plain hipMalloc; GATO_XMEM pins one): attempt(kind) -> (cluster, "") when every rank could export
+    and map the mirrors AND the first solve came back complete on every rank, else (None, reason).  Returns the first
+    cluster that works (or None) and what was tried before it.  A rejection for size ("do not fit") ends the search."""
+    tried = []
+    for kind in kinds:
+        c, err = attempt(kind)
+        if c is not None:
+            return c, "; ".join(tried)[:300]
+        tried.append(f"{kind}: {err}"[:120])
+        if "do not fit" in err:
+            break
+    return None, "; ".join(tried)[:300]
+
+
+def probe_cluster(cl, launch, expect_iters=None, group=None):
+    """One probe solve of a freshly connected cluster: launch(cl) enqueues this rank's persistent launch (NO collective
+    inside) and returns its `iters` tensor.  Whatever happens on this rank - an exception, a hand-off time-out (iters < 0,
+    sticky status) - the device is synchronised before the ranks meet, and every rank reaches the same AND.  Returns
+    (ok on ALL ranks, this rank's reason)."""
+    ok, err = True, ""
+    try:
+        it = launch(cl)
+        cl.sol.synchronize()
+        got = int(it.cpu()[0])
+        ok = got >= 0 if expect_iters is None else got == expect_iters
+        try:
+            cl.sol.check_status()
+        except Exception:         # noqa: BLE001
+            ok = False
+        if not ok:
+            err = "the first in-kernel exchange timed out"
+    except Exception as e:        # noqa: BLE001
+        ok, err = False, f"{type(e).__name__}: {e}"
+        try:
+            cl.sol.synchronize()          # the peers free / unmap their mirrors next: nothing of ours may still be storing into them
+        except Exception:         # noqa: BLE001
+            pass
+    if _all_ranks_ok(ok, group):
+        return True, ""
+    return False, err or "the first in-kernel exchange timed out on another rank"
+
+
+def connect_cluster(sol, rank, nranks, launch, group=None, expect_iters=None, kinds=None):
+    """Connected, probed ClusterPCG for this solver or ClusterUnavailable on EVERY rank (callers then take the RCCL
+    schedule).  Tries the mirror memory kinds in turn (env GATO_XMEM pins one).  Returns (cluster, what was rejected before)."""
+    import os
+    pinned = os.environ.get("GATO_XMEM")
+
+    def attempt(kind):
+        os.environ["GATO_XMEM"] = kind
+        try:
+            cl = ClusterPCG(sol, rank, nranks, group)
+        except ClusterUnavailable as e:
+            return None, f"mirrors unavailable: {e}"
+        ok, err = probe_cluster(cl, launch, expect_iters, group)
+        if ok:
+            return cl, ""
+        cl.close()
+        return None, err
+
+    try:
+        cl, why = first_working_kind([pinned] if pinned else list(kinds or MIRROR_KINDS), attempt)
+    finally:
+        if not pinned:
+            os.environ.pop("GATO_XMEM", None)
+    if cl is None:
+        raise ClusterUnavailable(why or "no mirror memory kind worked")
+    return cl, why
+
+
+class ClusterTimeout(ClusterUnavailable):
+    """A hand-off of a cluster solve timed out on some rank (raised on every rank alike; the outputs are not valid)."""
+
+
+def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None, state=None, check=True):
+    """Whole solve with the PCG sharded over the ranks of `group` through the in-kernel xGMI hand-off.  Assembly is SHARDED
+    too (assemble_shard: every rank forms the block rows its PCG shard reads plus the few halo knots they depend on), each
+    rank's launch solves its knot range, lambda and dz are assembled by one sum-all-reduce of the disjoint slices each per
+    solve (outside the iteration loop).  The first call connects the cluster (connect_cluster: memory kinds in turn, a
+    probe solve, ClusterUnavailable on every rank when the transport cannot be used).  With check (default) the call
+    synchronises at its end and raises ClusterTimeout on EVERY rank if any rank's launch reported a hand-off time-out
+    (iters = -1 / sticky status): the outputs are garbage then and the caller takes linsys_solve_sharded.
     `state` (returned as the last element) carries solver, device inputs and the connected cluster across calls."""
     import torch
     import torch.distributed as dist
     from .solver import Solver
-    """Assembly is SHARDED too (assemble_shard: every rank forms the block rows its PCG shard reads, plus the few halo
-    knots they depend on), so the whole step scales, not only the iteration loop."""
     rank, nranks = dist.get_rank(group), dist.get_world_size(group)
     if state is None:
         dev = torch.cuda.current_device() if device is None else device
         sol = Solver(sysm.S, sysm.C, sysm.K, dtype, dev)
-        state = dict(sol=sol, d=sol.upload_system(sysm), cl=ClusterPCG(sol, rank, nranks, group))
+        state = dict(sol=sol, d=sol.upload_system(sysm))
+
+        def probe(cl):
+            b = state["bufs"] = assemble_shard(sol, state["d"], sysm.rho, cl.k0, cl.k1, state.get("bufs"))
+            lam = torch.zeros(sol.S * sol.K, dtype=sol.dtype, device=b["Sb"].device)
+            it = torch.zeros(1, dtype=torch.int32, device=b["Sb"].device)
+            cl.pcg(b["Sb"], b["Pb"], b["gam"], exit_tol, max_iters, lam, it)
+            return it
+        try:
+            state["cl"], state["rejected"] = connect_cluster(sol, rank, nranks, probe, group)
+        except ClusterUnavailable:
+            sol.close()
+            raise
     sol, d, cl = state["sol"], state["d"], state["cl"]
     b = state["bufs"] = assemble_shard(sol, d, sysm.rho, cl.k0, cl.k1, state.get("bufs"))
     dev = b["Sb"].device
@@ -393,4 +489,35 @@ def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=Non
     allreduce_sum_(lam, group)                      # disjoint slices -> the whole lambda on every rank (once per solve)
     dz_shard(sol, d, b, lam, dz, cl.k0, cl.k1)
     allreduce_sum_(dz, group)
+    if check:
+        sol.synchronize()
+        ok = int(iters.cpu()[0]) >= 0
+        try:
+            sol.check_status()
+        except Exception:         # noqa: BLE001
+            ok = False
+        if not _all_ranks_ok(ok, group):
+            raise ClusterTimeout("a hand-off of the cluster solve timed out" + ("" if ok else " on this rank"))
+    return lam, dz, iters, state
+
+
+def linsys_solve_auto(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None, state=None):
+    """The product entry for a knot-sharded solve: the in-kernel transport when it can be connected and its solves come
+    back complete, else (every rank together) the RCCL all-gather schedule.  Returns (lambda, dz, iters, state);
+    state["transport"] says what ran."""
+    if state is None or state.get("transport") == "xgmi":
+        try:
+            lam, dz, iters, st = linsys_solve_cluster(sysm, exit_tol, max_iters, dtype, device, group, state)
+            st["transport"] = "xgmi"
+            return lam, dz, iters, st
+        except ClusterUnavailable as e:
+            if state is not None:                   # a connected cluster timed out later: drop it, keep going over RCCL
+                try:
+                    state["cl"].close()
+                    state["sol"].close()
+                except Exception:     # noqa: BLE001
+                    pass
+            state = dict(transport="rccl", why=str(e)[:300])
+    lam, dz, iters, sol = linsys_solve_sharded(sysm, exit_tol, max_iters, dtype, device, group)
+    sol.close()
     return lam, dz, iters, state

@@ -68,7 +68,7 @@ def main_batched(args, torch, dist, rank, local, world):
     el = _timed(lambda: sol.linsys_batched(*dev, 0.0, MAX_ITERS, base.rho, lam, dz, iters), args.steps, args.warmup, torch, dist)
     if rank == 0:
         val = MAX_ITERS * B * world * args.steps / el
-        print(json.dumps({"metric": "PCG iterations/s", "value": val, "unit": "iterations/s", "n_gpus": world,
+        print(dumps_strict({"metric": "PCG iterations/s", "value": val, "unit": "iterations/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f64" if dt == np.float64 else "f32", "data": "synthetic",
@@ -112,33 +112,21 @@ def replicas_leg(args, torch, dist, rank, local, world):
             "config": {"workload": name, "baseline_config": cfg, "STATE_SIZE": S, "CONTROL_SIZE": C, "KNOT_POINTS": K,
                        "max_iters": MAX_ITERS, "exit_tol": 0.0,
                        "step": "convert + Schur/stair assembly + PCG(100 iterations) + dz, inputs resident in HBM",
-                       "parallelism": f"replicas only: {world} independent systems, one per GPU, no data-path collective "
-                                      "(the sharded solves with a real exchange are in 'sharded')",
+                       "parallelism": f"replicas only: {world} independent systems, one per GPU, no data-path collective; "
+                                      "the knot-sharded solves (real exchange) are in config.sharded",
                        "pcg_kernel": "resident", "pcg_workgroups": groups, "pcg_threads": threads},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
-                         "traffic": None, "kernel": "pcg_resident (rank 0, per GPU)", "launch_ms": pcg_ms,
+                         "traffic": None, "limiter": "latency (matrices register/LDS-resident: HBM read once per launch)",
+                         "kernel": "pcg_resident (rank 0, per GPU)", "launch_ms": pcg_ms,
                          "algorithmic_bytes_per_launch": bytes_launch}}
 
 
-def first_working_kind(kinds, attempt):
-    """The mirrors of the in-kernel transport in each memory kind the library knows, in turn (uncached device memory, then
-    fine-grained, then plain hipMalloc; GATO_XMEM pins one): attempt(kind) -> (cluster, "") when every rank could export
-    and map the mirrors AND the first solve came back complete on every rank, else (None, reason).  Returns the first
-    cluster that works (or None) and what was tried before it.  A rejection for size ("do not fit") ends the search."""
-    tried = []
-    for kind in kinds:
-        c, err = attempt(kind)
-        if c is not None:
-            return c, "; ".join(tried)[:300]
-        tried.append(f"{kind}: {err}"[:120])
-        if "do not fit" in err:
-            break
-    return None, "; ".join(tried)[:300]
+from .dist import first_working_kind          # noqa: E402,F401  (tests import it from here too)
 
 
 def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
     from . import synth
-    from .dist import (ClusterPCG, ClusterUnavailable, HipShardBackend, ShardedPCG, _all_ranks_ok, allreduce_sum_, assemble_shard,
+    from .dist import (ClusterUnavailable, HipShardBackend, ShardedPCG, allreduce_sum_, assemble_shard, connect_cluster,
                        dz_shard)
     from .solver import Solver
     S, C, K, dt = WORKLOADS[name]
@@ -179,41 +167,19 @@ def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
         return lam, sol.compute_dz(Gi, Cd, d[6], lam), iters
 
     if want == "xgmi":
-        def attempt(kind):
-            """One memory kind: (cluster or None, reason it was rejected).  Every decision inside is an AND over the ranks."""
-            nonlocal cl
-            os.environ["GATO_XMEM"] = kind
-            try:
-                cl = ClusterPCG(sol, rank, world)
-            except ClusterUnavailable as e:
-                cl = None
-                return None, f"mirrors unavailable: {e}"
-            ok, err = True, ""
-            try:
-                _, _, it0 = step_xgmi()
-                torch.cuda.synchronize()
-                ok = int(it0.cpu()[0]) == MAX_ITERS
-                try:
-                    sol.check_status()
-                except Exception:     # noqa: BLE001
-                    ok = False
-                if not ok:
-                    err = "the first in-kernel exchange timed out"
-            except Exception as e:    # noqa: BLE001
-                ok, err = False, f"{type(e).__name__}: {e}"
-            if _all_ranks_ok(ok):
-                return cl, ""
-            cl.close()
-            cl = None
-            xb.clear()
-            return None, err or "the first in-kernel exchange timed out on another rank"
-
-        pinned = os.environ.get("GATO_XMEM")
-        cl, why = first_working_kind([pinned] if pinned else ["uncached", "finegrained", "plain"], attempt)
-        if not pinned:
-            os.environ.pop("GATO_XMEM", None)
-        if cl is not None:
+        def probe(c):
+            # this rank's launch alone (no collective inside): assembly of its rows + the persistent launch
+            b = xb["b"] = assemble_shard(sol, d, sysm.rho, c.k0, c.k1, xb.get("b"))
+            lam = torch.zeros(S * K, dtype=sol.dtype, device=dev)
+            it = torch.zeros(1, dtype=torch.int32, device=dev)
+            c.pcg(b["Sb"], b["Pb"], b["gam"], 0.0, MAX_ITERS, lam, it)
+            return it
+        try:
+            cl, why = connect_cluster(sol, rank, world, probe, expect_iters=MAX_ITERS)
             transport = "xgmi"
+        except ClusterUnavailable as e:
+            cl, why = None, str(e)[:300]
+            xb.clear()
     step = step_xgmi if transport == "xgmi" else step_rccl
     el = _timed(lambda: step(), steps, warmup, torch, dist)
     lam, dz, iters = step()
@@ -370,6 +336,48 @@ def rider_in_child(dist, rank, world, rider, steps, warmup, deadline):
 
 
 RIDER_KEYS = ("value", "unit", "ms_per_step", "scaling", "dtype", "config", "pcg_us_per_iter", "roofline", "parity")
+# the knot-sharded solves that ride along with the replicas line: configs[3] (K = 4096 over the ranks), configs[4]
+# (32/16/1024, "1 vs 8 GPUs") and the size where sharding can pay
+DEFAULT_RIDERS = ("sharded_k4096_f32", "sharded_s32_k1024_f32", "sharded_k262144_f32")
+LINE_LIMIT = 4096
+
+
+def dumps_strict(obj, limit=None):
+    import importlib
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in _sys.path:
+        _sys.path.insert(0, root)
+    return importlib.import_module("bench").dumps_strict(obj, limit)
+
+
+def rider_summary(r):
+    """What the last line keeps of one sharded rider: the strong-scaling numbers where a fixed-key parser
+    sees them - us per iteration of the sharded launch, the same system on ONE GPU, the transport that ran."""
+    if not isinstance(r, dict) or "error" in r or "value" not in r:
+        return {"error": str((r or {}).get("error", "no result"))[:120]}
+    par, cfg = r.get("parity") or {}, r.get("config") or {}
+    one_ips = par.get("same_system_on_one_gpu_iters_per_s")
+    return {"transport": cfg.get("transport"), "mirror_memory": cfg.get("mirror_memory"),
+            "fallback_reason": (cfg.get("transport_fallback_reason") or "")[:100] or None,
+            "knots_per_gpu": cfg.get("knots_per_gpu"), "workgroups_per_gpu": cfg.get("pcg_workgroups_per_gpu"),
+            "iters_per_s": r["value"], "us_per_iter": r.get("pcg_us_per_iter"), "ms_per_step": r.get("ms_per_step"),
+            "one_gpu_iters_per_s": one_ips, "one_gpu_us_per_iter": par.get("same_system_on_one_gpu_pcg_us_per_iter"),
+            "one_gpu_kernel": par.get("same_system_on_one_gpu_kernel"),
+            "speedup_vs_one_gpu": (r["value"] / one_ips) if one_ips else None,
+            "lam_rel_err_vs_one_gpu": par.get("lam_rel_err_vs_single_gpu"), "iters": par.get("iters")}
+
+
+def attach_riders(out, riders):
+    """Put the sharded results into `config` of the replicas line, flat keys first (configs[3])."""
+    cfg = out["config"]
+    cfg["sharded"] = {name: rider_summary(r) for name, r in riders.items()}
+    k4 = cfg["sharded"].get("sharded_k4096_f32", {})
+    cfg["transport"] = k4.get("transport")
+    cfg["sharded_k4096_us_per_iter"] = k4.get("us_per_iter")
+    cfg["same_system_one_gpu_us_per_iter"] = k4.get("one_gpu_us_per_iter")
+    cfg["sharded_k4096_speedup_vs_one_gpu"] = k4.get("speedup_vs_one_gpu")
+    return out
 
 
 def main(args):
@@ -393,7 +401,7 @@ def main(args):
         out = sharded_leg(args, torch, dist, rank, local, world, wl, args.steps, args.warmup)
         if rider_out and rank == 0:
             with open(rider_out + ".tmp", "w") as f:
-                f.write(json.dumps({k: out[k] for k in RIDER_KEYS}))
+                f.write(dumps_strict({k: out[k] for k in RIDER_KEYS}))
             os.replace(rider_out + ".tmp", rider_out)
             out = None
     else:
@@ -402,7 +410,7 @@ def main(args):
         # would put more processes on the card than a box allows, so it keeps them in this process
         inproc = os.environ.get("GATO_BENCH_RIDERS_INPROC") == "1" or (ONE_GPU and world > 3)
         riders = {}
-        for rider in ("sharded_k4096_f32", "sharded_k262144_f32"):
+        for rider in DEFAULT_RIDERS:
             if rider == "sharded_k262144_f32" and world < 2:
                 continue                                          # one GPU runs it through the streaming kernels: not a sharding number
             big = rider == "sharded_k262144_f32"
@@ -420,11 +428,11 @@ def main(args):
                 if rank == 0:
                     riders[rider] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if rank == 0:
-            out["sharded"] = riders.get("sharded_k4096_f32")
-            if "sharded_k262144_f32" in riders:
-                out["sharded_k262144_f32"] = riders["sharded_k262144_f32"]
+            attach_riders(out, riders)
+            for name, r in riders.items():                        # the full rider objects: EARLIER stdout lines, never the last
+                print(dumps_strict({"rider": name, "result": r}), flush=True)
     if rank == 0 and out is not None:
-        print(json.dumps(out), flush=True)
+        print(dumps_strict(out, LINE_LIMIT), flush=True)
     dist.destroy_process_group()
 
 

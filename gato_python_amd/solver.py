@@ -64,8 +64,16 @@ class Solver:
         _lib.check(_lib.lib().gato_solver_get_option(self._h, name.encode(), ct.byref(v)))
         return v.value
 
+    def tune(self):
+        """Measure the hosting XCD of the one-XCD launches for the geometry the CURRENT options plan (blocking, ~1 ms;
+        gato_solver_tune).  The constructor did it for the default geometry."""
+        _lib.check(_lib.lib().gato_solver_tune(self._h, self._stream()))
+
     def _stream(self):
         return ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
 
     def new(self, n, dtype=None):
         return torch.empty(int(n), dtype=dtype or self.dtype, device=f"cuda:{self.device}")

@@ -117,9 +117,18 @@ int gato_form_ss(gato_solver *s, const void *d_S, void *d_Pinv, void *stream);
 /* A4-A8  solve_pcg<T> (gato_pcg.cuh:476-567).  lambda is reset to 0 (D5: warm_start is a no-op in
  * the reference, gato_pcg.cuh:303).  d_iters receives the reference's iteration count (index of
  * the iteration that met |eta| < exit_tol, else max_iters; gato_pcg.cuh:311-313,:406-408; -1 = a hand-off of a
- * persistent launch timed out, see gato_pcg_status).  Asynchronous on `stream`. */
+ * persistent launch timed out, see gato_pcg_status).  Asynchronous on `stream`: enqueue only - no host wait, no
+ * trial launches, nothing but d_lambda / d_iters written for the caller (checked by
+ * tests/test_gpu_parity.py::test_pcg_entry_is_enqueue_only). */
 int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma,
              void *d_lambda, double exit_tol, int max_iters, int *d_iters, void *stream);
+/* Placement of the one-XCD persistent launches (2..32 workgroups; replaces nothing in the reference - its cooperative
+ * launch, gato_pcg.cuh:502-526, has no notion of placement): measures once which of the eight XCDs hosts the geometry the
+ * solver's CURRENT options plan (16 short trial launches on solver-owned scratch buffers, each waited for: BLOCKING,
+ * ~1 ms).  gato_solver_create calls it for the default geometry (env GATO_NO_TUNE=1 skips that); call it again after
+ * changing pcg_threads / pcg_groups / pcg_variant / max_workgroups / xcd_pack.  A geometry that was never measured runs
+ * on XCD 0; results never depend on the placement.  No-op for batches, cluster ranks and other geometries. */
+int gato_solver_tune(gato_solver *s, void *stream);
 /* Hand-off time-outs (the workgroups of a persistent launch were not co-resident - the case the reference excludes
  * with cudaLaunchCooperativeKernel + check_sms, gato_pcg.cuh:502-526, gato_utils.cuh:829-854): the launch writes
  * iters = -1 (in-band, no second call needed) and the id of the launch into the solver's status word, which no kernel

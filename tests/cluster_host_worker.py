@@ -50,6 +50,17 @@ class StubLib:
 
 class FakeSolver:
     K, _h = 64, None
+    status_bad = False
+
+    def synchronize(self):
+        pass
+
+    def check_status(self):
+        if self.status_bad:
+            raise RuntimeError("ETIMEOUT")
+
+    def close(self):
+        pass
 
 
 def main():
@@ -73,6 +84,44 @@ def main():
             _lib._LIB = real
     assert outcomes == ["unavailable", "unavailable", "unavailable", "ok"], outcomes
     assert gd._all_ranks_ok(True) is True and gd._all_ranks_ok(rank != 0) is False
+
+    # connect_cluster: mirrors in each memory kind in turn + a probe solve, every decision an AND over the ranks.
+    #  kind "uncached": the probe launch raises on rank 1; "finegrained": rank 0's launch reports a time-out in band
+    #  (iters = -1); "plain": every rank's launch completes -> taken, on every rank, with the two rejections recorded
+    import torch
+    stub = StubLib(real, False, False, True)
+    _lib._LIB = stub
+    seen = []
+
+    def launch(cl):
+        kind = os.environ["GATO_XMEM"]
+        seen.append(kind)
+        if kind == "uncached" and rank == 1:
+            raise RuntimeError("launch failed here only")
+        return torch.tensor([-1 if (kind == "finegrained" and rank == 0) else 7], dtype=torch.int32)
+    try:
+        os.environ.pop("GATO_XMEM", None)
+        cl, why = gd.connect_cluster(FakeSolver(), rank, world, launch)
+        assert seen == ["uncached", "finegrained", "plain"], seen
+        assert why.count("timed out") + why.count("launch failed") == 2, why
+        assert "GATO_XMEM" not in os.environ and cl is not None
+        # a sticky status on ONE rank (no in-band mark) rejects the kind on every rank; nothing left -> ClusterUnavailable everywhere
+        seen.clear()
+        sol = FakeSolver()
+        sol.status_bad = rank == 1
+        try:
+            gd.connect_cluster(sol, rank, world, launch, kinds=("plain",))
+            raise AssertionError("expected ClusterUnavailable")
+        except gd.ClusterUnavailable as e:
+            assert "timed out" in str(e)
+        # expect_iters: a launch that ends early is not a complete probe
+        try:
+            gd.connect_cluster(FakeSolver(), rank, world, launch, expect_iters=100, kinds=("plain",))
+            raise AssertionError("expected ClusterUnavailable")
+        except gd.ClusterUnavailable:
+            pass
+    finally:
+        _lib._LIB = real
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}/{world} ok {outcomes}")

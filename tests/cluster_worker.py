@@ -44,12 +44,18 @@ def main():
         assert abs(it - it_o) <= (0 if f64 else 2), (it, it_o)
         mine = lam.cpu().numpy()[cl.k0 * S:cl.k1 * S]
         err = np.abs(mine - lam_o[cl.k0 * S:cl.k1 * S]).max() / np.abs(lam_o).max()
-        assert err < (1e-9 if f64 else 5e-3), err
+        assert err < (1e-9 if f64 else 2e-3), err         # one rank's slice (the assembled solution is judged below)
         # the slices of all ranks assemble the full solution
         full = lam.cpu()
         dist.all_reduce(full)
         errf = np.abs(full.numpy() - lam_o).max() / np.abs(lam_o).max()
-        assert errf < (1e-9 if f64 else 5e-3), errf
+        if f64:
+            assert errf < 1e-9, errf
+        else:       # fp32: measured against the converged fp64 solution of the same matrices, beside the fp32 oracle's error
+            truth = co.pcg(Sb.astype(np.float64), Pb.astype(np.float64), gam.astype(np.float64), S, K, 1e-14, 600)[0]
+            den = np.abs(truth).max()
+            eg, eo = np.abs(full.numpy() - truth).max() / den, np.abs(lam_o.astype(np.float64) - truth).max() / den
+            assert eg <= 2.0 * eo + 5e-6, (eg, eo)
     mem = sol.get_option("cluster_mem_kind")
     groups, threads = sol.get_option("last_groups"), sol.get_option("last_threads")
     dist.barrier()

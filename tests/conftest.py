@@ -21,3 +21,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _dump_f32_parity_log():
+    """Every measured fp32 pair of the session (tests/f32_parity.py) -> gpurun_out/f32_parity.json."""
+    yield
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    import f32_parity
+    f32_parity.dump()

@@ -39,39 +39,68 @@ def _need_gpu():
     _lib.lib()                                    # the HIP library must be the thing that runs
 
 
-# ---- fp32 parity, measured instead of assumed ---------------------------------------------------------------------
-# The reference computes in fp32.  An fp32 result is judged against the fp64 oracle run on the SAME
-# (fp32-rounded) inputs: err_gpu = |x_gpu32 - x_64| / |x_64| beside err_oracle = |x_oracle32 - x_64| / |x_64|, the error
-# the reference's own arithmetic makes in the oracle's (= the reference's) accumulation order.  The HIP kernels sum in
-# another order (MFMA tiles, DPP trees, two rows per lane), so the bar is err_gpu <= F32_FACTOR * err_oracle + F32_FLOOR.
-# Every pair is appended to gpurun_out/f32_parity.json (DESIGN.md section 4 quotes the measured maxima).
-F32_FACTOR, F32_FLOOR = 2.0, 5e-6     # floor: ~40 fp32 ulps (the pendulum run iterates past convergence: 5.2e-6 vs 1.4e-6)
-_F32_LOG = []
-
-
-def check_f32(what, gpu, oracle32, truth64, factor=F32_FACTOR, floor=F32_FLOOR):
-    if not (np.all(np.isfinite(truth64)) and np.all(np.isfinite(oracle32))):
-        return
-    eg, eo = rel(np.asarray(gpu, np.float64), truth64), rel(np.asarray(oracle32, np.float64), truth64)
-    _F32_LOG.append(dict(what=what, err_gpu=float(eg), err_oracle=float(eo)))
-    assert eg <= factor * eo + floor, (what, eg, eo)
-
-
-@pytest.fixture(scope="module", autouse=True)
-def _dump_f32_log():
-    yield
-    if _F32_LOG:
-        import json
-        out = os.path.join(ROOT, "gpurun_out")
-        os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "f32_parity.json"), "w") as f:
-            json.dump(dict(factor=F32_FACTOR, floor=F32_FLOOR, max_ratio=max(e["err_gpu"] / max(e["err_oracle"], F32_FLOOR) for e in _F32_LOG),
-                           entries=_F32_LOG), f, indent=1)
+from f32_parity import check_f32                # noqa: E402  (tests/f32_parity.py: the measured fp32 bar and its log)
 
 
 def make_solver(S, C, K, dt):
     from gato_python_amd.solver import Solver
     return Solver(S, C, K, dt)
+
+
+def _f32_truth_inputs(s):
+    """The fp32-rounded inputs of a system as fp64 arrays + the fp32-rounded rho: what an fp32 run really solves."""
+    return s.astype(np.float32).astype(np.float64), float(np.float32(s.rho))
+
+
+def check_solve(tag, s, S, C, K, dt, tol, mi, lam, dz, it=None, it_slack=2, rerun=None, f64_tol=1e-8):
+    """A whole solve (CSR in, lambda / dz out) against the C oracle's whole solve on the same inputs.
+    fp64: the oracle's iteration count, lambda and dz to f64_tol.
+    fp32: iteration count within it_slack of the fp32 oracle's; lambda and dz judged by check_f32 against the CONVERGED
+    fp64 solution of the fp32-rounded system, beside the fp32 oracle's own error (both were stopped by the same test).
+    If the exit iterations differ and `rerun(tol, mi) -> (lam, dz)` is given, the comparison is repeated at the FIXED
+    iteration count both reached (exit_tol = 0), against the fp64 iterates after that many iterations.
+    Returns the oracle's iteration count."""
+    lam, dz = np.asarray(lam), np.asarray(dz)
+    lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
+    if np.dtype(dt) == np.float64:
+        if it is not None:
+            assert it == it_o, (tag, it, it_o)
+        assert rel(lam, lam_o) < f64_tol and rel(dz, dz_o) < f64_tol, (tag, rel(lam, lam_o), rel(dz, dz_o))
+        return it_o
+    if it is not None:
+        assert abs(it - it_o) <= it_slack, (tag, it, it_o)
+    s64, rho32 = _f32_truth_inputs(s)
+    lam_t, dz_t, _ = co.linsys_solve(*s64.csr_args(), S, C, K, 1e-14, max(600, 2 * mi), rho32, dtype=np.float64)
+    check_f32(f"solve lambda {tag}", lam, lam_o, lam_t)
+    check_f32(f"solve dz {tag}", dz, dz_o, dz_t)
+    if it is not None and it != it_o and rerun is not None:
+        n = min(it, it_o) + 1                                  # iterations both runs completed (iters = 0-based exit index)
+        n = min(n, mi)
+        lam_f, dz_f = rerun(0.0, n)
+        lam_of, dz_of, _ = co.linsys_solve(*s.csr_args(), S, C, K, 0.0, n, s.rho, dtype=np.float32)
+        lam_tf, dz_tf, _ = co.linsys_solve(*s64.csr_args(), S, C, K, 0.0, n, rho32, dtype=np.float64)
+        check_f32(f"solve lambda after {n} fixed iterations {tag}", lam_f, lam_of, lam_tf)
+        check_f32(f"solve dz after {n} fixed iterations {tag}", dz_f, dz_of, dz_tf)
+    return it_o
+
+
+def check_pcg(tag, Sb, Pb, gam, S, K, tol, mi, lam, it=None, it_slack=2, f64_tol=1e-9):
+    """A PCG run on given (oracle-assembled) matrices against the C oracle's PCG on the same matrices: fp64 to f64_tol with
+    the oracle's iteration count; fp32 by check_f32 against the fp64 iteration on the same fp32 matrices - at the same
+    fixed count when exit_tol = 0, else against the converged fp64 solution."""
+    lam = np.asarray(lam)
+    lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, tol, mi)
+    if Sb.dtype == np.float64:
+        if it is not None:
+            assert it == it_o, (tag, it, it_o)
+        assert rel(lam, lam_o) < f64_tol, (tag, rel(lam, lam_o))
+        return it_o
+    if it is not None:
+        assert abs(it - it_o) <= it_slack, (tag, it, it_o)
+    S64, P64, g64 = Sb.astype(np.float64), Pb.astype(np.float64), gam.astype(np.float64)
+    truth = co.pcg(S64, P64, g64, S, K, 0.0, mi)[0] if tol == 0.0 else co.pcg(S64, P64, g64, S, K, 1e-14, max(600, 2 * mi))[0]
+    check_f32(f"pcg {tag}", lam, lam_o, truth)
+    return it_o
 
 
 def system(S, C, K, seed=0, dq=False):
@@ -277,7 +306,8 @@ def test_unused_boundary_blocks_are_never_read():
         sol.close()
 
 
-@pytest.mark.parametrize("S,C,K,dt", [(14, 7, 4096, np.float64), (14, 7, 4096, np.float32), (32, 16, 1024, np.float64)])
+@pytest.mark.parametrize("S,C,K,dt", [(14, 7, 4096, np.float64), (14, 7, 4096, np.float32), (32, 16, 1024, np.float64),
+                                      (32, 16, 1024, np.float32)])
 def test_full_size_properties(S, C, K, dt):
     """BASELINE sizes: the returned (lambda, dz) satisfy the KKT equations
          (G + rho I) dz + C^T lambda = g,   C dz = c
@@ -302,15 +332,33 @@ def test_full_size_properties(S, C, K, dt):
     assert np.abs(r1).max() / scale < (1e-10 if f64 else 1e-4)
     # the constraint residual is the Schur-system residual left by the exit test |r.Pinv r| < tol
     assert np.abs(r2).max() / max(np.abs(d).max(), 1.0) < (5e-6 if f64 else 1e-3)
-    lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
-    assert rel(l, lam_o) < (1e-8 if f64 else 2e-2)
-    # streaming variant gives the same answer
+    # against the oracle's whole solve: its iteration count; BASELINE's bar ||dz - dz_ref||inf < 1e-6 in fp64 (dz = O(1..10)
+    # here, so the absolute bar is the tighter one); fp32 measured beside the fp32 oracle's own error (check_f32)
+    it = int(np.frombuffer(_read_iters(sol), np.int32)[0])
+
+    def rerun_on(solver):
+        def rerun(tol_, mi_):
+            a, b = solver.new(S * K), solver.new(solver.N)
+            solver.linsys(*dev, tol_, mi_, s.rho, a, b)
+            torch.cuda.synchronize()
+            solver.check_status()
+            return host(a), host(b)
+        return rerun
+    it_o = check_solve(f"full size {S}/{C}/{K}", s, S, C, K, dt, tol, mi, l, d, it, rerun=rerun_on(sol))
+    if f64:
+        _, dz_o, _ = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
+        assert np.abs(d - dz_o).max() < 1e-6, np.abs(d - dz_o).max()
+    # streaming variant: the same checks against the oracle (not only against the resident launch)
     sol2 = make_solver(S, C, K, dt)
     sol2.set_option("pcg_mode", _lib.PCG_STREAMING)
     lam2, dz2 = sol2.new(S * K), sol2.new(sol2.N)
     sol2.linsys(*dev, tol, mi, s.rho, lam2, dz2)
     torch.cuda.synchronize()
-    assert rel(host(lam2), l) < (1e-8 if f64 else 2e-2)
+    sol2.check_status()
+    it2 = int(np.frombuffer(_read_iters(sol2), np.int32)[0])
+    check_solve(f"full size {S}/{C}/{K} streaming", s, S, C, K, dt, tol, mi, host(lam2), host(dz2), it2, rerun=rerun_on(sol2))
+    if f64:
+        assert it2 == it_o and np.abs(host(dz2) - dz_o).max() < 1e-6
     sol.close()
     sol2.close()
 
@@ -324,9 +372,7 @@ def test_dropin_accepts_numpy_and_env_shape(monkeypatch):
                                          np.zeros(700), 2, 1e-6, 100, False, s.rho)
     finally:
         gpu_library.clear_problem_size()
-    lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), 14, 7, 50, 1e-6, 100, s.rho, dtype=np.float32)
-    assert abs(gpu_library.last_stats()["iters"] - it_o) <= 2
-    assert rel(l, lam_o) < 5e-3 and rel(dz, dz_o) < 5e-3
+    check_solve("drop-in 14/7/50", s, 14, 7, 50, np.float32, 1e-6, 100, np.asarray(l), np.asarray(dz), gpu_library.last_stats()["iters"])
     with pytest.raises(ValueError):
         gpu_library.set_problem_size(14, 7, 49)
         try:
@@ -385,17 +431,25 @@ def test_true_warm_start(S, C, K, dt, opts):
     # default: reference behaviour, the initial guess is ignored
     lam = sol.to_device(lam0)
     lam, it = sol.pcg(dS, dP, dg, tol, 300, lam=lam)
-    assert abs(int(host(it)[0]) - it_c) <= (0 if f64 else 2) and rel(host(lam), lam_c) < (1e-9 if f64 else 5e-3)
+    check_pcg(f"warm start ignored {S}/{C}/{K} {opts}", out["S"], out["Pinv"], out["gamma"], S, K, tol, 300, host(lam), int(host(it)[0]))
     # opt-in: true warm start
     sol.set_option("true_warm_start", 1)
     lam = sol.to_device(lam0)
     lam, it = sol.pcg(dS, dP, dg, tol, 300, lam=lam)
     assert abs(int(host(it)[0]) - it_w) <= (0 if f64 else 2), (int(host(it)[0]), it_w)
-    assert rel(host(lam), lam_w) < (1e-9 if f64 else 5e-3)
+    if f64:
+        assert rel(host(lam), lam_w) < 1e-9
+    else:           # fp32: against the converged fp64 solution of the same fp32 matrices, beside the numpy restatement's error
+        conv = co.pcg(out["S"].astype(np.float64), out["Pinv"].astype(np.float64), out["gamma"].astype(np.float64), S, K, 1e-14, 600)[0]
+        check_f32(f"true warm start {S}/{C}/{K} {opts}", host(lam), lam_w, conv)
     # starting from the converged solution: exits at once
     lam = sol.to_device(lam_w)
     lam2, it = sol.pcg(dS, dP, dg, tol * 1e4, 300, lam=lam)
-    assert int(host(it)[0]) <= 1 and rel(host(lam2), lam_w) < (1e-5 if f64 else 5e-3)   # one more step is taken before the test
+    assert int(host(it)[0]) <= 1                                                       # one more step is taken before the test
+    if f64:
+        assert rel(host(lam2), lam_w) < 1e-5
+    else:
+        check_f32(f"warm start from the solution {S}/{C}/{K} {opts}", host(lam2), lam_w, conv)
     sol.close()
 
 
@@ -418,9 +472,7 @@ def test_batched_solves(S, C, K, B, dt):
     lam_h, dz_h, it_h = host(lam).reshape(B, -1), host(dz).reshape(B, -1), host(iters)
     for b in (range(B) if B <= 40 else list(range(0, B, 37)) + [B - 1]):
         s = systems[b]
-        lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
-        assert abs(int(it_h[b]) - it_o) <= (0 if f64 else 2), (b, int(it_h[b]), it_o)
-        assert rel(lam_h[b], lam_o) < (1e-8 if f64 else 5e-3) and rel(dz_h[b], dz_o) < (1e-8 if f64 else 5e-3)
+        check_solve(f"batch {S}/{C}/{K} system {b} of {B}", s, S, C, K, dt, tol, mi, lam_h[b], dz_h[b], int(it_h[b]))
     assert sol.get_option("batch") == B
     sol.close()
 
@@ -500,7 +552,7 @@ def test_one_xcd_placement_is_a_hint_only():
             sol.set_option(k, v)
         dev = sol.upload_system(s)
         lam, dz = sol.new(S * K), sol.new(sol.N)
-        for _ in range(2):                                   # the first call of a solver calibrates, the second does not
+        for _ in range(2):                                   # (the solver measured its placement at creation: gato_solver_tune)
             sol.linsys(*dev, 1e-5, 60, s.rho, lam, dz)
             sol.check_status()
         sel = sol.get_option("last_xcd_sel")
@@ -514,6 +566,60 @@ def test_one_xcd_placement_is_a_hint_only():
             ref = (host(lam).copy(), host(dz).copy())
         assert np.array_equal(host(lam), ref[0]) and np.array_equal(host(dz), ref[1]), opts
         sol.close()
+
+
+def test_pcg_entry_is_enqueue_only():
+    """gato_pcg / gato_linsys_device are documented as asynchronous (include/gato_hip.h): enqueue only.  The XCD placement
+    of the one-XCD launches is measured in gato_solver_create / gato_solver_tune (blocking, solver-owned scratch), never in
+    the entry: with ~60 ms of earlier work queued on the stream the call must return while that work is still running -
+    for the default geometry (measured at creation) and for a geometry nobody measured (runs on XCD 0) - and an explicit
+    tune() afterwards changes the placement only, not a bit of the result, the caller's buffers or the sticky status."""
+    import time
+    S, C, K = 14, 7, 512
+    s = synth.make_system(S, C, K, seed=3)
+    sol = make_solver(S, C, K, np.float32)
+    dev = sol.upload_system(s)
+    lam, dz = sol.new(S * K), sol.new(sol.N)
+    sol.linsys(*dev, 0.0, 40, s.rho, lam, dz)                     # warm the code objects up
+    torch.cuda.synchronize()
+    assert 0 <= sol.get_option("last_xcd_sel") <= 7                  # measured at creation, no launch of the caller needed
+    ref = (host(lam).copy(), host(dz).copy())
+    stream = torch.cuda.current_stream()
+    t0 = time.perf_counter()                                         # what one tick of torch.cuda._sleep lasts on this box
+    torch.cuda._sleep(2_000_000)
+    torch.cuda.synchronize()
+    per_tick = (time.perf_counter() - t0) / 2_000_000
+    ticks = int(0.06 / per_tick)
+    for geometry in ("default", "unmeasured"):
+        if geometry == "unmeasured":
+            sol.set_option("pcg_threads", 448)                       # another geometry: 16 workgroups, no measurement for it
+        lam.zero_()
+        dz.zero_()
+        torch.cuda.synchronize()
+        torch.cuda._sleep(ticks)
+        t0 = time.perf_counter()
+        sol.linsys(*dev, 0.0, 40, s.rho, lam, dz)
+        dt_call = time.perf_counter() - t0
+        busy = not stream.query()
+        torch.cuda.synchronize()
+        sol.check_status()
+        assert busy and dt_call < 0.03, (geometry, busy, dt_call)     # returned while the queued work was still running
+        if geometry == "default":
+            assert np.array_equal(host(lam), ref[0]) and np.array_equal(host(dz), ref[1])
+        else:
+            assert sol.get_option("last_xcd_sel") == 0 and sol.get_option("last_groups") > 15
+            unmeasured = (host(lam).copy(), host(dz).copy())
+    # explicit tune for the new geometry: blocking, touches neither the caller's buffers nor the status
+    lam.fill_(7.0)
+    dz.fill_(7.0)
+    sol.tune()
+    assert float(lam.min()) == 7.0 and float(dz.max()) == 7.0
+    sol.check_status()
+    sol.linsys(*dev, 0.0, 40, s.rho, lam, dz)
+    torch.cuda.synchronize()
+    assert 0 <= sol.get_option("last_xcd_sel") <= 7
+    assert np.array_equal(host(lam), unmeasured[0]) and np.array_equal(host(dz), unmeasured[1])
+    sol.close()
 
 
 def test_c_host_example():
@@ -537,8 +643,7 @@ def test_direct_block_input(S, C, K, dt, dq):
     lam, dz = sol.new(S * K), sol.new(sol.N)
     sol.linsys_blocks(sol.to_device(Gd0), sol.to_device(Cd), sol.to_device(s.g), sol.to_device(s.c), tol, mi, s.rho, lam, dz)
     torch.cuda.synchronize()
-    lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
-    assert rel(host(lam), lam_o) < (1e-8 if f64 else 5e-3) and rel(host(dz), dz_o) < (1e-8 if f64 else 5e-3)
+    check_solve(f"block input {S}/{C}/{K}", s, S, C, K, dt, tol, mi, host(lam), host(dz), int(np.frombuffer(_read_iters(sol), np.int32)[0]))
     sol.close()
 
 
@@ -567,8 +672,12 @@ def test_single_reduction_variant(S, C, K, dt, opts):
     assert sol.get_option("last_variant") == 1
     assert abs(int(host(it)[0]) - it_cg) <= (0 if f64 else 2), (int(host(it)[0]), it_cg, it_ref)
     assert abs(int(host(it)[0]) - it_ref) <= 2
-    assert rel(host(lam), lam_cg) < (1e-8 if f64 else 5e-3)
-    assert rel(host(lam), lam_ref) < (1e-6 if f64 else 5e-3)
+    if f64:
+        assert rel(host(lam), lam_cg) < 1e-8 and rel(host(lam), lam_ref) < 1e-6
+    else:           # fp32: the converged fp64 solution of the same matrices is the truth for both recurrences
+        conv = co.pcg(Sb.astype(np.float64), Pb.astype(np.float64), gam.astype(np.float64), S, K, 1e-14, 600)[0]
+        check_f32(f"single-reduction variant vs its restatement {S}/{C}/{K}", host(lam), lam_cg, conv)
+        check_f32(f"single-reduction variant vs the reference recurrence {S}/{C}/{K}", host(lam), lam_ref, conv)
     lam2, it2 = sol.pcg(dS, dP, dg, tol, 300)
     assert torch.equal(lam, lam2) and torch.equal(it, it2)        # deterministic
     sol.close()
@@ -587,8 +696,7 @@ def test_other_compiled_shapes(S, C, K, dt):
     sol.linsys(*dev, tol, mi, s.rho, lam, dz)
     torch.cuda.synchronize()
     sol.check_status()
-    lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
-    assert rel(host(lam), lam_o) < (1e-8 if f64 else 5e-3) and rel(host(dz), dz_o) < (1e-8 if f64 else 5e-3)
+    check_solve(f"shape {S}/{C}/{K}", s, S, C, K, dt, tol, mi, host(lam), host(dz), int(np.frombuffer(_read_iters(sol), np.int32)[0]))
     sol.close()
 
 
@@ -751,6 +859,7 @@ def test_semi_resident_kernel_matches_the_streaming_kernels(S, C, K, dt, which):
     workgroups and tiles (K = 13901, K = 65531)."""
     s = system(S, C, K, 17)
     f64 = dt == np.float64
+    tol = 1e-9 if f64 else 1e-4
     res = {}
     for semi in (which, 0):
         sol = make_solver(S, C, K, dt)
@@ -758,7 +867,7 @@ def test_semi_resident_kernel_matches_the_streaming_kernels(S, C, K, dt, which):
         sol.set_option("record_eta", 1)
         dev = sol.upload_system(s)
         lam, dz = sol.new(S * K), sol.new(sol.N)
-        sol.linsys(*dev, 1e-9 if f64 else 1e-4, 40, s.rho, lam, dz)
+        sol.linsys(*dev, tol, 40, s.rho, lam, dz)
         sol.check_status()
         it = int(np.frombuffer(_read_iters(sol), np.int32)[0])
         assert sol.get_option("last_semi") == semi
@@ -766,16 +875,37 @@ def test_semi_resident_kernel_matches_the_streaming_kernels(S, C, K, dt, which):
         res[semi] = (host(lam).copy(), host(dz).copy(), it, sol.eta_history(min(it + 1, 40)))
         if semi:                                              # a second solve on the same solver: fresh epochs, same bits
             lam2, dz2 = sol.new(S * K), sol.new(sol.N)
-            sol.linsys(*dev, 1e-9 if f64 else 1e-4, 40, s.rho, lam2, dz2)
+            sol.linsys(*dev, tol, 40, s.rho, lam2, dz2)
             sol.check_status()
             assert np.array_equal(host(lam2), res[semi][0])
+
+            # DIRECTLY against the C oracle (these launches used to meet only the streaming kernels):
+            # the oracle's exit iteration and solution, and 12 fixed iterations against the oracle's iterates
+            def rerun(tol_, mi_):
+                a, b = sol.new(S * K), sol.new(sol.N)
+                sol.linsys(*dev, tol_, mi_, s.rho, a, b)
+                sol.check_status()
+                assert sol.get_option("last_semi") == semi
+                return host(a), host(b)
+            tag = f"persistent launch variant {which} at {S}/{C}/{K}"
+            check_solve(tag, s, S, C, K, dt, tol, 40, res[semi][0], res[semi][1], it, it_slack=1, rerun=rerun, f64_tol=1e-9)
+            lam12, dz12 = rerun(0.0, 12)
+            lam_o, dz_o, it_o = co.linsys_solve(*s.csr_args(), S, C, K, 0.0, 12, s.rho, dtype=dt)
+            if f64:
+                assert rel(lam12, lam_o) < 1e-10 and rel(dz12, dz_o) < 1e-10
+            else:
+                s64, rho32 = _f32_truth_inputs(s)
+                lam_t, dz_t, _ = co.linsys_solve(*s64.csr_args(), S, C, K, 0.0, 12, rho32, dtype=np.float64)
+                check_f32(f"lambda after 12 iterations, {tag}", lam12, lam_o, lam_t)
+                check_f32(f"dz after 12 iterations, {tag}", dz12, dz_o, dz_t)
         sol.close()
+    # and against the streaming kernels on the same assembled system: same iterates, same exit iteration
     (la, da, ia, ea), (lb, db, ib, eb) = res[which], res[0]
     assert abs(ia - ib) <= (0 if f64 else 1), (ia, ib)
     n = min(len(ea), len(eb), 8)
-    assert np.allclose(ea[:n], eb[:n], rtol=1e-9 if f64 else 2e-3)
-    if ia == ib:
-        assert rel(la, lb) < (1e-10 if f64 else 5e-4) and rel(da, db) < (1e-10 if f64 else 5e-4)
+    assert np.allclose(ea[:n], eb[:n], rtol=1e-9 if f64 else 2e-3)          # eta = r.Pinv r: a cancelling sum in fp32
+    if f64:
+        assert ia == ib and rel(la, lb) < 1e-10 and rel(da, db) < 1e-10
 
 
 def _read_iters(sol):
@@ -809,7 +939,14 @@ def test_pcg_degenerate_iteration_counts_and_geometries(S, C, K, dt, tol, mi, op
     lam, it = sol.pcg(sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam), tol, mi)
     assert int(host(it)[0]) == it_o
     scale = max(float(np.abs(lam_o).max()), 1e-30)
-    assert float(np.abs(host(lam).astype(np.float64) - lam_o).max()) / scale < (1e-10 if dt == np.float64 else 2e-3)
+    if dt == np.float64:
+        assert float(np.abs(host(lam) - lam_o).max()) / scale < 1e-10
+    elif scale > 1e-30:       # fp32: same number of steps as the oracle (asserted above) -> the fp64 iterates after that many steps
+        n = mi if it_o == mi else it_o + 1
+        truth = co.pcg(Sb.astype(np.float64), Pb.astype(np.float64), gam.astype(np.float64), S, K, 0.0, n)[0]
+        check_f32(f"degenerate {S}/{C}/{K} tol {tol} max_iters {mi} {opts}", host(lam), lam_o, truth)
+    else:
+        assert not np.any(host(lam))
     sol.close()
 
 
@@ -877,7 +1014,8 @@ def test_thirteen_workgroups_of_64_threads_1000_launches():
             assert np.array_equal(got, first) and int(host(it)[0]) == 20
     sol.check_status()
     assert sol.get_option("last_groups") == 13 and sol.get_option("last_threads") == 64
-    assert rel(first, lam_o) < 2e-3
+    check_f32("13 x 64 threads, 20 iterations", first, lam_o,
+              co.pcg(Sb.astype(np.float64), Pb.astype(np.float64), gam.astype(np.float64), S, K, 0.0, 20)[0])
     sol.close()
 
 
@@ -905,8 +1043,7 @@ def test_three_concurrent_multi_workgroup_solves_on_three_streams():
     for i in range(3):
         sols[i].check_status()
         assert sols[i].get_option("last_groups") > 100
-        assert abs(int(host(its[i])[0]) - it_o) <= 2
-        assert rel(host(lams[i]), lam_o) < 5e-3
+        check_pcg(f"three concurrent launches, stream {i}", Sb, Pb, gam, S, K, 1e-4, 60, host(lams[i]), int(host(its[i])[0]))
         sols[i].close()
 
 
@@ -963,20 +1100,50 @@ def test_preconditioner_modes(S, C, K, dt, mode):
     assert int(np.frombuffer(_read_iters(sol), np.int32)[0]) == n_it
     if f64:
         assert rel(host(lam), out["lam"]) < 1e-9 and rel(host(dz), out["dz"]) < 1e-9
-    elif mode == _lib.PRECON_BLOCK_JACOBI:   # fp32: judged against the fp64 iterates, beside the fp32 oracle's error
-        t = o.linsys_solve(*s.csr_args(), S, C, K, 0.0, n_it, s.rho, dtype=np.float64, return_all=True, precon_mode=mode)
-        check_f32(f"precon mode {mode} {S}/{C}/{K} lambda after {n_it}", host(lam), out["lam"], t["lam"], floor=1e-4)
-    # (fp32 point-Jacobi: 15 iterations of barely preconditioned CG in single precision differ by percents between any two
-    #  summation orders - the oracle's own error against fp64 is 8e-3 there; only Pinv and the converged solve are compared)
-    # to tolerance: a weaker preconditioner needs more iterations (their number depends on rounding when convergence is
-    # slow: within 5 % of the oracle's) and reaches the same solution
+    else:
+        # fp32: judged against the fp64 iterates after the same number of iterations, beside the fp32 oracle's error.
+        # Block-Jacobi: at n_it.  Point-Jacobi at 32/16/9 is barely preconditioned CG on 288 unknowns and loses its
+        # conjugacy in single precision between iterations 10 and 15: the error of the SAME recurrence against fp64 is
+        # 4e-6 after 10 iterations, 8e-5 after 12 and 6e-2 (C oracle's summation order) / 8e-3 (numpy oracle's order) after
+        # 15 - two CPU orders 8x apart (tests/test_oracle.py::test_fp32_point_jacobi_is_order_chaotic_past_ten_iterations).
+        # So the GPU is held to the 2x bar where the iteration is still deterministic to rounding (5 and 10 iterations),
+        # and at 15 to the worse of the two CPU orders.
+        s64, rho32 = _f32_truth_inputs(s)
+
+        def after(n):
+            sol.linsys(*dev, 0.0, n, s.rho, lam, dz)
+            sol.check_status()
+            t = o.linsys_solve(*s64.csr_args(), S, C, K, 0.0, n, rho32, dtype=np.float64, return_all=True, precon_mode=mode)
+            a = o.linsys_solve(*s.csr_args(), S, C, K, 0.0, n, s.rho, dtype=np.float32, return_all=True, precon_mode=mode)
+            c = co.pcg(a["S"], a["Pinv"], a["gamma"], S, K, 0.0, n)[0]          # the C oracle's order on the same fp32 matrices
+            return host(lam).copy(), a["lam"], c, t["lam"]
+        if mode == _lib.PRECON_BLOCK_JACOBI:
+            g, a, c, t = after(n_it)
+            check_f32(f"precon mode {mode} {S}/{C}/{K} lambda after {n_it}", g, a, t, floor=1e-4)
+        else:
+            for n in (5, 10):
+                g, a, c, t = after(n)
+                worse = a if rel(a, t) >= rel(c, t) else c
+                check_f32(f"precon mode {mode} {S}/{C}/{K} lambda after {n}", g, worse, t)
+            g, a, c, t = after(15)
+            worse = a if rel(a, t) >= rel(c, t) else c
+            check_f32(f"precon mode {mode} {S}/{C}/{K} lambda after 15 (order-chaotic)", g, worse, t)
+    # to tolerance: a weaker preconditioner needs more iterations and reaches the same solution.  Their number depends on
+    # rounding when convergence is slow: the two CPU restatements themselves differ by one there (point-Jacobi fp64 14/7/50:
+    # numpy order 99, C order 100; 14/7/600: 161 / 160), so point-Jacobi gets max(2, 2 %) and block-Jacobi in fp64 none
     tol, mi = (1e-9, 3000) if f64 else (1e-4, 400)
     out = o.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt, return_all=True, precon_mode=mode)
     sol.linsys(*dev, tol, mi, s.rho, lam, dz)
     sol.check_status()
     it = int(np.frombuffer(_read_iters(sol), np.int32)[0])
-    assert abs(it - out["iters"]) <= max(2, out["iters"] // 20), (it, out["iters"])
-    assert rel(host(lam), out["lam"]) < (1e-5 if f64 else 2e-2)
+    slack = max(2, out["iters"] // 50) if (mode == _lib.PRECON_POINT_JACOBI or not f64) else 0
+    assert abs(it - out["iters"]) <= slack, (it, out["iters"])
+    if f64:
+        assert rel(host(lam), out["lam"]) < 1e-5
+    else:
+        s64, rho32 = _f32_truth_inputs(s)
+        conv = o.linsys_solve(*s64.csr_args(), S, C, K, 1e-14, 3000, rho32, dtype=np.float64, return_all=True, precon_mode=mode)
+        check_f32(f"precon mode {mode} {S}/{C}/{K} lambda at the exit test", host(lam), out["lam"], conv["lam"])
     ms = sol.last_stage_ms()
     assert ms["assembly"] > 0 and ms["pcg"] > 0 and ms["dz"] > 0
     sol.close()
@@ -1024,6 +1191,5 @@ def test_dz_in_the_pcg_epilogue_is_bit_identical_to_the_dz_launch(S, C, K, dt, B
         res[nofuse] = (host(lam).copy(), host(dz).copy())
         sol.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
-    lam_o, dz_o, _ = co.linsys_solve(*s.csr_args(), S, C, K, 1e-9, 60, s.rho, dtype=dt)
-    f64 = dt == np.float64
-    assert rel(res[0][1][:len(dz_o)], dz_o) < (1e-9 if f64 else 5e-3)
+    n_dz = (S + C) * K - C
+    check_solve(f"dz in the PCG epilogue {S}/{C}/{K} x{B}", s, S, C, K, dt, 1e-9, 60, res[0][0][:S * K], res[0][1][:n_dz], f64_tol=1e-9)

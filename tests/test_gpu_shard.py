@@ -38,8 +38,13 @@ def test_shard_kernels_lockstep(S, C, K, R, dt):
     torch.cuda.synchronize()
     its = [int(i.cpu()[0]) for i in iters]
     assert len(set(its)) == 1 and abs(its[0] - it_o) <= (0 if f64 else 2), (its, it_o)
-    err = np.abs(lam.cpu().numpy() - lam_o).max() / np.abs(lam_o).max()
-    assert err < (1e-9 if f64 else 5e-3), err
+    if f64:
+        err = np.abs(lam.cpu().numpy() - lam_o).max() / np.abs(lam_o).max()
+        assert err < 1e-9, err
+    else:           # fp32: measured against the converged fp64 solution of the same matrices (tests/f32_parity.py)
+        from f32_parity import check_f32
+        truth = co.pcg(Sb.astype(np.float64), Pb.astype(np.float64), gam.astype(np.float64), S, K, 1e-14, 600)[0]
+        check_f32(f"{R} lock-step shards {S}/{C}/{K}", lam.cpu().numpy(), lam_o, truth)
     assert all(b.done() for b in bes) == (its[0] < mi)              # the host-side convergence poll agrees
     for x in sols:
         x.close()
@@ -53,7 +58,7 @@ def test_bench_sharded_leg_world1():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["workload"].startswith("sharded")
-    assert d["parity"]["lam_rel_err_vs_single_gpu"] < 5e-3
+    assert d["parity"]["lam_rel_err_vs_single_gpu"] < 1e-3      # two fp32 HIP runs of 100 fixed iterations (a plumbing check)
 
 
 def test_bench_batched_leg_world1():
@@ -74,6 +79,14 @@ def test_bench_default_multi_gpu_line_world1():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["scaling"] == "weak" and d["n_gpus"] == 1 and d["value"] > 1e5 and d["dtype"] == "f64"
     assert d["config"]["workload"] == "iiwa_14_7_k50_f64" and 0 < d["roofline"]["frac"] < 1
-    sh = d["sharded"]
-    assert sh["scaling"] == "strong" and sh["config"]["workload"] == "sharded_k4096_f32" and sh["value"] > 0
-    assert sh["parity"]["lam_rel_err_vs_single_gpu"] < 5e-3
+    # the LAST line is the compact headline (< 4 KB, strict JSON) with the sharded riders' strong-scaling numbers in config;
+    # the full rider objects are earlier lines
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096
+    cfg = d["config"]
+    sh = cfg["sharded"]["sharded_k4096_f32"]
+    assert sh["iters_per_s"] > 0 and sh["transport"] in ("xgmi", "rccl") and cfg["transport"] == sh["transport"]
+    assert sh["one_gpu_us_per_iter"] > 0 and sh["lam_rel_err_vs_one_gpu"] < 1e-3 and sh["iters"] == 100
+    assert cfg["sharded"]["sharded_s32_k1024_f32"]["iters_per_s"] > 0                     # configs[4] rides along too
+    full = [json.loads(x) for x in r.stdout.strip().splitlines()[:-1] if x.startswith('{"rider"')]
+    assert {x["rider"] for x in full} == set(cfg["sharded"]) and all(x["result"]["scaling"] == "strong" for x in full)

@@ -110,3 +110,73 @@ def test_transport_search_over_mirror_memory_kinds():
     calls.clear()
     c, why = first_working_kind(["uncached", "finegrained"], lambda k: (calls.append(k), (None, "mirrors unavailable: 9 knots over 2 ranks do not fit one launch"))[1])
     assert c is None and calls == ["uncached"]
+
+
+def _canned_result():
+    lf = {"us_per_iteration": 1.42, "products_us": 0.99, "reductions_and_handoffs_us": 0.43, "diagnostic_build_full_us": 1.97,
+          "loop_skeleton_us": 0.43, "production_us_per_iteration": 2.044, "frac_of_floor": float("nan"),
+          "handoff_floor_us": 0.59, "us_per_iteration_with_handoff_floor": 2.17}
+    return dict(workload="iiwa_14_7_k50_f64", S=14, C=7, K=50, dtype="f64", iters_per_s=453210.98765432, ms_per_step=0.22064,
+                timed_steps=1140, latency_floor=lf, pcg_launch_ms=0.2044, pcg_launch_ms_min=0.2031,
+                pcg_iters_per_s=489236.79, pcg_us_per_iter=2.044, pcg_mode="resident (one workgroup, mixed 2/1 rows per lane)",
+                pcg_groups=1, pcg_threads=512, algorithmic_bytes_per_launch=53692800, achieved_gbs=262.68)
+
+
+def test_bench_headline_is_compact_strict_json():
+    """the driver parses the LAST stdout line of bench.py and keeps only a tail of stdout, so that line
+    must be one strict-JSON object under 4 KB with metric / value / roofline / cpu_baseline, whatever the sweep holds."""
+    import bench
+    res = _canned_result()
+    traffic, src = bench.committed_traffic("iiwa_14_7_k50_f64", res)
+    cpu = {"value": 35123.4, "unit": "PCG iterations/s", "cores": 1, "kind": "port", "sample": "x" * 150,
+           "tried": [{"cores": 1, "value": 35123.4}, {"cores": 16, "value": 21000.0}],
+           "secondary": {"value": 36000.0, "unit": "PCG iterations/s", "cores": 1, "kind": "scipy", "sample": "y" * 60}}
+    out = bench.headline(res, "iiwa_14_7_k50_f64", 20, 5, traffic, src, cpu, "gpurun_out/bench_sweep.json")
+    # the full r02 sweep had 15 entries: give the line as many summaries
+    out["sweep"] = {f"workload_number_{i}_with_a_long_name_f32": bench.sweep_summary(dict(res, roofline_frac=0.89 if i % 2 else None))
+                    for i in range(16)}
+    line = bench.dumps_strict(out, bench.LINE_LIMIT)
+    assert len(line) < 4096 and "\n" not in line and "NaN" not in line and "Infinity" not in line
+    back = json.loads(line, parse_constant=lambda c: pytest.fail(f"non-strict constant {c}"))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in back
+    assert back["config"]["workload"] == "iiwa_14_7_k50_f64" and back["vs_baseline"] is None and back["dtype"] == "f64"
+    ro = back["roofline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / 8000.0) < 1e-6
+    assert abs(ro["traffic"] - traffic) < 1.0 and ro["traffic_over_algorithmic"] < 0.05 and ro["limiter"].startswith("latency")
+    assert ro["latency_floor"]["frac_of_floor"] is None           # NaN -> null
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(back["cpu_baseline"])
+    # a launch that streams its matrices every iteration is reported as HBM-limited
+    hb = dict(res, algorithmic_bytes_per_launch=1000, achieved_gbs=7000.0)
+    assert bench.roofline_object(hb, 900, "x")["limiter"] == "hbm"
+    with pytest.raises(ValueError):
+        bench.dumps_strict({"x": "y" * 5000}, bench.LINE_LIMIT)
+
+
+def test_bench_multi_gpu_line_carries_the_sharded_results_compactly():
+    """the --gpus N line keeps the replicas value comparable with N = 1 and carries the strong-scaling
+    results of the knot-sharded riders in `config`, under 4 KB, strict JSON - also when a rider failed."""
+    import bench
+    from gato_python_amd import dist_bench as db
+    assert "sharded_s32_k1024_f32" in db.DEFAULT_RIDERS and "sharded_k4096_f32" in db.DEFAULT_RIDERS
+    rider = {"value": 181000.0, "unit": "iterations/s", "ms_per_step": 0.55, "scaling": "strong", "dtype": "f32",
+             "config": {"workload": "sharded_k4096_f32", "transport": "xgmi", "transport_fallback_reason": "", "mirror_memory": "uncached",
+                        "knots_per_gpu": 2048, "pcg_workgroups_per_gpu": 57, "parallelism": "p" * 300},
+             "pcg_us_per_iter": 5.3, "roofline": {"bound": "hbm", "achieved": 4000.0, "frac": 0.25},
+             "parity": {"lam_rel_err_vs_single_gpu": 3e-7, "dz_abs_err_vs_single_gpu": 1e-6, "iters": 100,
+                        "same_system_on_one_gpu_iters_per_s": 231000.0, "same_system_on_one_gpu_pcg_us_per_iter": 3.86,
+                        "same_system_on_one_gpu_kernel": "resident"}}
+    out = {"metric": "PCG iterations/s", "value": 9e5, "unit": "iterations/s", "n_gpus": 2, "steps": 20, "warmup": 5,
+           "ms_per_step": 0.22, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "iiwa_14_7_k50_f64", "parallelism": "replicas only: " + "r" * 150},
+           "roofline": {"bound": "hbm", "achieved": 262.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.0328, "traffic": None}}
+    db.attach_riders(out, {"sharded_k4096_f32": rider, "sharded_s32_k1024_f32": dict(rider),
+                           "sharded_k262144_f32": {"error": "rider child job did not deliver (exit 1, deadline 240 s)", "log_tail": "z" * 400}})
+    line = bench.dumps_strict(out, db.LINE_LIMIT)
+    back = json.loads(line)
+    cfg = back["config"]
+    assert cfg["transport"] == "xgmi" and cfg["sharded_k4096_us_per_iter"] == 5.3 and cfg["same_system_one_gpu_us_per_iter"] == 3.86
+    assert set(cfg["sharded"]) == set(db.DEFAULT_RIDERS)
+    assert abs(cfg["sharded"]["sharded_s32_k1024_f32"]["speedup_vs_one_gpu"] - 181.0 / 231.0) < 1e-5
+    assert "error" in cfg["sharded"]["sharded_k262144_f32"] and len(line) < 4096
