@@ -108,6 +108,7 @@ struct gato_solver {
     int num_cus;
     // options
     int pcg_mode, pcg_threads, pcg_groups;
+    int wave_pub;                       // option: per-wave published partials in launches of up to 32 workgroups (default 1)
     // arena
     char *arena;
     size_t arena_bytes;
@@ -359,6 +360,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     s->pcg_mode = GATO_PCG_AUTO;
     s->xcd_pack = -1;
     s->xcd_sel = -1;
+    s->wave_pub = 1;
     s->pcg_semi = -1;
     s->timeout_ms = 2000;
     s->cluster_flat = 1;
@@ -461,6 +463,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "ablate")) s->ablate = value;
     else if (!strcmp(name, "no_single_lds")) s->no_single_lds = value;
     else if (!strcmp(name, "no_pair")) s->no_pair = value;
+    else if (!strcmp(name, "wave_pub")) s->wave_pub = value;
     else if (!strcmp(name, "pcg_variant")) s->pcg_variant = value;
     else if (!strcmp(name, "record_eta")) s->record_eta = value;
     else if (!strcmp(name, "xcd_pack")) s->xcd_pack = value;
@@ -792,6 +795,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         }
         if (a.semi) a.xcd_pack = 0;
         a.xcd_sel = s->xcd_sel;
+        a.wave_pub = s->wave_pub;
         if (a.xcd_pack > 0 && groups > s->num_cus / 8) a.xcd_pack = 0;     // an XCD with fewer CUs than workgroups (CU mask): plain grid
         a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
         a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
@@ -1535,6 +1539,7 @@ extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_P
     a.lambda0 = s->true_warm_start ? d_lambda : nullptr;
     a.K = s->d.K; a.max_iters = max_iters; a.exit_tol = exit_tol;
     a.batch = 1; a.semi = s->plan_semi;
+    a.wave_pub = s->wave_pub;
     a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
     a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
     a.epoch0 = s->pcg_epoch; s->pcg_epoch += need;

@@ -159,6 +159,7 @@ struct PcgLaunch {
     int pair;                    // fp32 one-workgroup kernel with two rows per lane
     int xcd_pack;                // 2..32 workgroups: place them on one XCD (grid 8x oversubscribed, 7 of 8 blocks exit)
     int xcd_sel;                 // 0..7: the XCD (blockIdx % 8) that hosts them
+    int wave_pub;                // launches of 2..32 workgroups: every wave publishes its own partial (no gather barrier); 0 = gathered form
     int knots_per_wg;            // contiguous knots owned by each workgroup (last may own fewer)
     int groups;                  // W = gridDim.x
     int threads;                 // blockDim.x (multiple of 64, >= knots_per_wg * S unless semi)

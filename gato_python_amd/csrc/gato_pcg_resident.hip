@@ -119,9 +119,18 @@ __device__ __forceinline__ T row_from_memory(const T *__restrict__ src, const T 
 // epoch; totals are summed in rank order (identical on every rank => identical exit decision).  The grid barriers of
 // the reference (gato_pcg.cuh:363,378,393,428) thus become two device-initiated all-gathers per iteration across the
 // node, no host involvement, no collective library inside the loop.
-template <typename T, int S, int MAXT, int NL = 0, int DIAG = 0, int XR = 0, bool NR = false, bool MR = false>
+// WP: launches of 2..32 workgroups of the plain variant.  EVERY WAVE publishes its own partial (one granule per wave in line 0
+// of the workgroup's slot - still one writing workgroup per line) and the polling wave of every workgroup reads W x waves
+// granules: the same W lines as before, coalesced.  The gather of the workgroup's total in wave 0 (LDS write, barrier B1, LDS
+// read, second DPP sum) leaves the critical path of the hand-off and an iteration has four barriers instead of six.  (Not the
+// "every wave polls" form that DESIGN.md 3.1 records as a dead end: one polling wave per workgroup it stays.)  The ghost
+// blocks of r and p live in registers of the polling lanes (lanes 0..S-1 left, 32..32+S-1 right) - no staging array, no LDS
+// read-modify-write on the way to the next product.  A compile-time variant: as a run-time switch in the one kernel the
+// extra scalar paths cost every launch 3-5 % (measured, same box: 14/7/512 f32 2.93 -> 3.02 us per iteration).
+template <typename T, int S, int MAXT, int NL = 0, int DIAG = 0, int XR = 0, bool NR = false, bool MR = false, bool WP = false>
 __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 {
+    static_assert(!WP || (NL == 0 && XR == 0 && !NR && !MR), "wave-published partials: plain variant only");
     // DIAG: 0 = production; 1 = cycle stamps + the timing-only switches of a.ablate; 2 = the switches alone (what
     // bench.py's latency floor times: the stamps cost registers, and this instantiation has none to spare)
     constexpr bool STAMP = DIAG == 1, ABL = DIAG != 0;
@@ -327,6 +336,10 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     }
     __syncthreads();
 
+    T g_r_init = (T)0;
+    if constexpr (WP) {                     // ghost r starts as the neighbours' gamma blocks (just written to the window)
+        if (wave == 0 && (lane < S || (lane >= 32 && lane < 32 + S))) g_r_init = xs[1][lane < 32 ? lane : (nk + 1) * SP + (lane - 32)];
+    }
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0, t_begin = 0, rt_begin = 0;
     if (STAMP) {
@@ -343,13 +356,20 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // lane's dot contribution.  On return: total in every thread; gh[][] = neighbours' boundary
     // blocks of `val` (zeros where there is no neighbour).
     const int abl = ABL ? a.ablate : 0;   // diagnostic timing-only switches, compiled out of the production build
+    // WP: the ghost blocks of r and p and the boundary entry just gathered, in the polling lanes' registers
+    T hv_reg = (T)0, g_r = g_r_init, g_p = (T)0;
+    const bool g_lane = WP && wave == 0 && (lane < S || (lane >= 32 && lane < 32 + S));
+    const int gslot = lane < 32 ? lane : (nk + 1) * SP + (lane - 32);      // the lane's ghost entry in an operand window
     auto allreduce_and_halo = [&](T val, T prod, T &total) {
         ++epoch;
         if constexpr (MR) ++xepoch;
         if (abl & 4) { total = (T)1 + prod * (T)1e-30; return; }
         T *wp = wpart[epoch & 1];
-        partials_store(wp, wave, lane, prod);
         gu64 *mine = slots + ((size_t)(epoch & 1) * W + wg) * slotG;
+        if constexpr (WP) {
+            const T ws = wave_sum(prod);
+            if (lane == 0) Gr::store(mine + wave * GPV, epoch, ws);
+        } else partials_store(wp, wave, lane, prod);
         if (!NR && W > 1 && active) {
             if (j == 0) Gr::store(mine + 16 + r_ * GPV, epoch, val);
             if (j == nk - 1) Gr::store(mine + 16 + (S + r_) * GPV, epoch, val);
@@ -360,7 +380,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 if (x_right && j == nk - 1) XGr::store(xp_next + (size_t)(xepoch & 1) * xslotG + xghL + r_ * GPV, xepoch, val);
             }
         }
-        __syncthreads();                                                       // B1
+        if constexpr (!WP) __syncthreads();                                    // B1
         if constexpr (NR) {                 // boundary blocks of the vector just formed: from the product array (complete after B1)
             if (W > 1) {
                 if (tid < S) Gr::store(mine + 16 + tid * GPV, epoch, xst[1][tid]);
@@ -380,10 +400,13 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             return;
         }
         if (wave == 0) {
-            T tot = partials_total<T, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
+            T tot = (T)0;
+            if constexpr (!WP) tot = partials_total<T, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
             bool fail = false;
             if (W > 1) {
-                if (lane == 0) Gr::store(mine, epoch, tot);
+                if constexpr (!WP) {
+                    if (lane == 0) Gr::store(mine, epoch, tot);
+                }
                 // sweep: partials of all workgroups + neighbours' halo blocks.  Every lane issues ALL its loads
                 // back to back from clamped (always valid) addresses and waits once: predicated loads would each
                 // get their own s_waitcnt, i.e. one L2 round trip after the other.
@@ -398,10 +421,22 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 gu64 *hptr = want_l ? pbase + (size_t)(wg - 1) * slotG + 16 + (S + ln) * GPV
                            : want_r ? pbase + (size_t)(wg + 1) * slotG + 16 + (ln - 32) * GPV
                                     : mine;
+                // gathered form: entry e = workgroup e's total.  WP: entry e = wave (e & mask) of workgroup (e >> wsh); entries of
+                // waves that do not exist read the workgroup's wave 0 and count as zero
                 gu64 *pptr[Cfg::PM];
+                int pm_count = (W + 63) >> 6;                 // wave-uniform
+                int wsh = 0;
+                if constexpr (WP) {
+                    wsh = nwaves <= 1 ? 0 : 32 - __builtin_clz((unsigned)(nwaves - 1));
+                    pm_count = ((W << wsh) + 63) >> 6;
+                }
 #pragma unroll
-                for (int m = 0; m < Cfg::PM; ++m) pptr[m] = pbase + (size_t)min(ln + 64 * m, W - 1) * slotG;
-                const int pm_count = (W + 63) >> 6;           // wave-uniform
+                for (int m = 0; m < Cfg::PM; ++m) {
+                    if constexpr (WP) {
+                        const int e = ln + 64 * m, wi = e >> wsh, wv = e & ((1 << wsh) - 1);
+                        pptr[m] = pbase + (size_t)min(wi, W - 1) * slotG + (wv < nwaves ? wv : 0) * GPV;
+                    } else pptr[m] = pbase + (size_t)min(ln + 64 * m, W - 1) * slotG;
+                }
                 unsigned long long raw[Cfg::PM][GPV], hraw[GPV];
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 // Cross-XCD launches: the first poll can never hit (the publishers' stores need a fabric round
@@ -439,15 +474,24 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 }
                 T pv[Cfg::PM];
 #pragma unroll
-                for (int m = 0; m < Cfg::PM; ++m)
-                    pv[m] = (m < pm_count && lane + 64 * m < W) ? Gr::decode(raw[m]) : (T)0;
+                for (int m = 0; m < Cfg::PM; ++m) {
+                    bool on = m < pm_count && lane + 64 * m < W;
+                    if constexpr (WP) {
+                        const int e = lane + 64 * m;
+                        on = m < pm_count && (e >> wsh) < W && (e & ((1 << wsh) - 1)) < nwaves;
+                    }
+                    pv[m] = on ? Gr::decode(raw[m]) : (T)0;
+                }
                 const T hv = Gr::decode(hraw);
                 T acc = (T)0;
 #pragma unroll
                 for (int m = 0; m < Cfg::PM; ++m) acc += pv[m];
                 tot = wave_sum(acc);
-                if (lane < S) gh[0][lane] = want_l ? hv : (T)0;
-                if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = want_r ? hv : (T)0;
+                if constexpr (WP) hv_reg = (want_l || want_r) ? hv : (T)0;
+                else {
+                    if (lane < S) gh[0][lane] = want_l ? hv : (T)0;
+                    if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = want_r ? hv : (T)0;
+                }
             } else {                       // one workgroup on this GPU (cluster launch): the ghosts come from level 2 only
                 if (lane < S) gh[0][lane] = (T)0;
                 if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = (T)0;
@@ -650,8 +694,13 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         if (multi) {
             T dummy;
             exchange(r, (T)0, dummy);
-            if (tid < S) xs[1][tid] = gh[0][tid];
-            else if (tid < 2 * S) xs[1][(nk + 1) * SP + (tid - S)] = gh[1][tid - S];
+            if constexpr (WP) {
+                g_r = hv_reg;
+                if (g_lane) xs[1][gslot] = g_r;
+            } else {
+                if (tid < S) xs[1][tid] = gh[0][tid];
+                else if (tid < 2 * S) xs[1][(nk + 1) * SP + (tid - S)] = gh[1][tid - S];
+            }
         }
         // the p window is rebuilt from r~ below; clear what lambda0 left in its ghost slots
         if (tid < S) xs[0][tid] = (T)0;
@@ -676,8 +725,13 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             if (q < n_ext_rows) xs[0][(xk + q / S + 1) * SP + q % S] = xst[1][q];
         }
         if (multi) {
-            if (tid < S) xs[0][tid] = gh[0][tid];
-            else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = gh[1][tid - S];
+            if constexpr (WP) {
+                g_p = hv_reg;
+                if (g_lane) xs[0][gslot] = g_p;
+            } else {
+                if (tid < S) xs[0][tid] = gh[0][tid];
+                else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = gh[1][tid - S];
+            }
         }
         __syncthreads();
 
@@ -709,8 +763,13 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 }
             }
             if (multi) {   // ghost r advances with the neighbours' upsilon blocks
-                if (tid < S) xs[1][tid] -= alpha * gh[0][tid];
-                else if (tid < 2 * S) xs[1][(nk + 1) * SP + (tid - S)] -= alpha * gh[1][tid - S];
+                if constexpr (WP) {
+                    g_r -= alpha * hv_reg;
+                    if (g_lane) xs[1][gslot] = g_r;
+                } else {
+                    if (tid < S) xs[1][tid] -= alpha * gh[0][tid];
+                    else if (tid < 2 * S) xs[1][(nk + 1) * SP + (tid - S)] -= alpha * gh[1][tid - S];
+                }
             }
             if (!(abl & 8)) __syncthreads();                                    // B3
             GATO_STAMP(2)
@@ -740,8 +799,13 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 }
             }
             if (multi) {
-                if (tid < S) xs[0][tid] = gh[0][tid] + beta * xs[0][tid];
-                else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = gh[1][tid - S] + beta * xs[0][(nk + 1) * SP + (tid - S)];
+                if constexpr (WP) {
+                    g_p = hv_reg + beta * g_p;
+                    if (g_lane) xs[0][gslot] = g_p;
+                } else {
+                    if (tid < S) xs[0][tid] = gh[0][tid] + beta * xs[0][tid];
+                    else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = gh[1][tid - S] + beta * xs[0][(nk + 1) * SP + (tid - S)];
+                }
             }
             eta = eta_new;                                                      // :420
             if (!(abl & 8)) __syncthreads();                                    // B6
@@ -1353,7 +1417,12 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
             return GATO_OK;
         }
     }
-    if (mr) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false, 0, false, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
+    // launches of 2..32 workgroups: the wave-published form (its sweep is W << ceil(log2(waves)) granules: at most 4 loads per lane)
+    const int nw_ = a.threads / 64, wsh_ = nw_ <= 1 ? 0 : 32 - __builtin_clz((unsigned)(nw_ - 1));
+    const bool wp = !mr && !a.stamps && a.diag != 2 && a.batch <= 1 && a.wave_pub != 0 && a.groups > 1 && a.groups <= 32 &&
+                    nw_ * (int)(sizeof(T) / 4) <= 16 && (a.groups << wsh_) <= 256;
+    if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, false, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
+    else if (mr) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false, 0, false, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
     else if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 1>), dim3(nblocks), dim3(a.threads), 0, st, a);
     else if (a.diag == 2) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2>), dim3(nblocks), dim3(a.threads), 0, st, a);
     else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false>), dim3(nblocks), dim3(a.threads), 0, st, a);

@@ -20,11 +20,21 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-def check_f32(what, gpu, oracle32, truth64, factor=F32_FACTOR, floor=F32_FLOOR):
+def check_f32(what, gpu, oracle32, truth64, factor=F32_FACTOR, floor=F32_FLOOR, second_order32=None):
+    """second_order32: the same fp32 recurrence summed in ANOTHER CPU order (the numpy restatement beside the C one), for
+    the few cases that are order-chaotic by construction - a tiny system iterated past convergence, barely preconditioned
+    CG past its loss of conjugacy (tools/past_convergence.py, tests/test_oracle.py::test_fp32_point_jacobi_...): there the
+    two CPU orders themselves are up to 10x apart in either direction, and the GPU is held to the worse of the two."""
     if not (np.all(np.isfinite(truth64)) and np.all(np.isfinite(oracle32))):
         return
     eg, eo = rel(np.asarray(gpu, np.float64), truth64), rel(np.asarray(oracle32, np.float64), truth64)
-    LOG.append(dict(what=what, err_gpu=float(eg), err_oracle=float(eo)))
+    entry = dict(what=what, err_gpu=float(eg), err_oracle=float(eo))
+    if second_order32 is not None:
+        e2 = rel(np.asarray(second_order32, np.float64), truth64)
+        entry["err_oracle_second_order"] = float(e2)
+        eo = max(eo, e2)
+        entry["err_oracle"] = float(eo)
+    LOG.append(entry)
     assert eg <= factor * eo + floor, (what, eg, eo)
 
 
