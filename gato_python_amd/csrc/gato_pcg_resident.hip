@@ -127,10 +127,15 @@ __device__ __forceinline__ T row_from_memory(const T *__restrict__ src, const T 
 // blocks of r and p live in registers of the polling lanes (lanes 0..S-1 left, 32..32+S-1 right) - no staging array, no LDS
 // read-modify-write on the way to the next product.  A compile-time variant: as a run-time switch in the one kernel the
 // extra scalar paths cost every launch 3-5 % (measured, same box: 14/7/512 f32 2.93 -> 3.02 us per iteration).
-template <typename T, int S, int MAXT, int NL = 0, int DIAG = 0, int XR = 0, bool NR = false, bool MR = false, bool WP = false>
+// WPM = poll loads per lane of that form (0 = the gathered form): 4 serves W << ceil(log2(waves)) <= 256 granules (up to 32
+// workgroups of 8 waves).  Measured and rejected: 16 loads per lane for up to 128 workgroups (14/7/4096 f32, W = 114: 4.77 us
+// per iteration against 3.87 gathered - fifteen load instructions per sweep cost more than the gather they replace).
+template <typename T, int S, int MAXT, int NL = 0, int DIAG = 0, int XR = 0, bool NR = false, bool MR = false, int WPM = 0>
 __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 {
-    static_assert(!WP || (NL == 0 && XR == 0 && !NR && !MR), "wave-published partials: plain variant only");
+    constexpr bool WP = WPM > 0;            // per-wave published partials
+    constexpr bool RG = WPM != 0;           // ghost blocks in the polling lanes' registers (WPM = -1: that alone, gathered partials)
+    static_assert(!RG || (NL == 0 && XR == 0 && !NR && DIAG != 1), "wave-published partials / register ghosts: plain and cluster variants");
     // DIAG: 0 = production; 1 = cycle stamps + the timing-only switches of a.ablate; 2 = the switches alone (what
     // bench.py's latency floor times: the stamps cost registers, and this instantiation has none to spare)
     constexpr bool STAMP = DIAG == 1, ABL = DIAG != 0;
@@ -143,6 +148,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // XCDs): a workgroup's slot is a whole number of 128-B lines (16 granules), the partial has line 0 to itself
     static_assert(MAXT % 64 == 0 && 2 * S * GPV <= 16 * ((2 * S * GPV + 15) / 16), "slot layout");
     static_assert(!MR || (NL == 0 && DIAG == 0), "cluster launches use the plain and the semi-resident variants");
+    static_assert(DIAG == 0 || !MR, "diagnostic builds are single-GPU");
 
     constexpr int MAXKX = NR ? Cfg::MAXK * XR : Cfg::MAXK * (1 + XR);          // local knots incl. the extra ones
     static_assert(NL == 0 || XR == 0, "the LDS-tail variant is single-workgroup only");
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     __syncthreads();
 
     T g_r_init = (T)0;
-    if constexpr (WP) {                     // ghost r starts as the neighbours' gamma blocks (just written to the window)
+    if constexpr (RG) {                     // ghost r starts as the neighbours' gamma blocks (just written to the window)
         if (wave == 0 && (lane < S || (lane >= 32 && lane < 32 + S))) g_r_init = xs[1][lane < 32 ? lane : (nk + 1) * SP + (lane - 32)];
     }
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     const int abl = ABL ? a.ablate : 0;   // diagnostic timing-only switches, compiled out of the production build
     // WP: the ghost blocks of r and p and the boundary entry just gathered, in the polling lanes' registers
     T hv_reg = (T)0, g_r = g_r_init, g_p = (T)0;
-    const bool g_lane = WP && wave == 0 && (lane < S || (lane >= 32 && lane < 32 + S));
+    const bool g_lane = RG && wave == 0 && (lane < S || (lane >= 32 && lane < 32 + S));
     const int gslot = lane < 32 ? lane : (nk + 1) * SP + (lane - 32);      // the lane's ghost entry in an operand window
     auto allreduce_and_halo = [&](T val, T prod, T &total) {
         ++epoch;
@@ -367,8 +373,10 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         T *wp = wpart[epoch & 1];
         gu64 *mine = slots + ((size_t)(epoch & 1) * W + wg) * slotG;
         if constexpr (WP) {
-            const T ws = wave_sum(prod);
-            if (lane == 0) Gr::store(mine + wave * GPV, epoch, ws);
+            if (W > 1) {
+                const T ws = wave_sum(prod);
+                if (lane == 0) Gr::store(mine + wave * GPV, epoch, ws);
+            } else partials_store(wp, wave, lane, prod);      // one workgroup per rank (cluster): its total comes from LDS
         } else partials_store(wp, wave, lane, prod);
         if (!NR && W > 1 && active) {
             if (j == 0) Gr::store(mine + 16 + r_ * GPV, epoch, val);
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 if (x_right && j == nk - 1) XGr::store(xp_next + (size_t)(xepoch & 1) * xslotG + xghL + r_ * GPV, xepoch, val);
             }
         }
-        if constexpr (!WP) __syncthreads();                                    // B1
+        if (!WP || W == 1) __syncthreads();                                    // B1
         if constexpr (NR) {                 // boundary blocks of the vector just formed: from the product array (complete after B1)
             if (W > 1) {
                 if (tid < S) Gr::store(mine + 16 + tid * GPV, epoch, xst[1][tid]);
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         }
         if (wave == 0) {
             T tot = (T)0;
-            if constexpr (!WP) tot = partials_total<T, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
+            if (!WP || W == 1) tot = partials_total<T, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
             bool fail = false;
             if (W > 1) {
                 if constexpr (!WP) {
@@ -423,7 +431,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                                     : mine;
                 // gathered form: entry e = workgroup e's total.  WP: entry e = wave (e & mask) of workgroup (e >> wsh); entries of
                 // waves that do not exist read the workgroup's wave 0 and count as zero
-                gu64 *pptr[Cfg::PM];
+                constexpr int PMX = WP ? WPM : Cfg::PM;
+                gu64 *pptr[PMX];
                 int pm_count = (W + 63) >> 6;                 // wave-uniform
                 int wsh = 0;
                 if constexpr (WP) {
@@ -431,13 +440,13 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                     pm_count = ((W << wsh) + 63) >> 6;
                 }
 #pragma unroll
-                for (int m = 0; m < Cfg::PM; ++m) {
+                for (int m = 0; m < PMX; ++m) {
                     if constexpr (WP) {
                         const int e = ln + 64 * m, wi = e >> wsh, wv = e & ((1 << wsh) - 1);
                         pptr[m] = pbase + (size_t)min(wi, W - 1) * slotG + (wv < nwaves ? wv : 0) * GPV;
                     } else pptr[m] = pbase + (size_t)min(ln + 64 * m, W - 1) * slotG;
                 }
-                unsigned long long raw[Cfg::PM][GPV], hraw[GPV];
+                unsigned long long raw[PMX][GPV], hraw[GPV];
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 // Cross-XCD launches: the first poll can never hit (the publishers' stores need a fabric round
                 // trip), and W*W early loads only queue in front of those stores.  ~0.35 us of sleep before the
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 if (W > 32) __builtin_amdgcn_s_sleep(12);
                 for (unsigned spin = 0;; ++spin) {
 #pragma unroll
-                    for (int m = 0; m < Cfg::PM; ++m) {
+                    for (int m = 0; m < PMX; ++m) {
                         if (m < pm_count) {
 #pragma unroll
                             for (int g = 0; g < GPV; ++g)
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                         hraw[g] = __hip_atomic_load(hptr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     bool ok = true;
 #pragma unroll
-                    for (int m = 0; m < Cfg::PM; ++m) {
+                    for (int m = 0; m < PMX; ++m) {
                         if (m < pm_count) {
 #pragma unroll
                             for (int g = 0; g < GPV; ++g) ok &= (unsigned)(raw[m][g] >> 32) == epoch;
@@ -472,9 +481,9 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                         if (late || other) { fail = true; break; }
                     }
                 }
-                T pv[Cfg::PM];
+                T pv[PMX];
 #pragma unroll
-                for (int m = 0; m < Cfg::PM; ++m) {
+                for (int m = 0; m < PMX; ++m) {
                     bool on = m < pm_count && lane + 64 * m < W;
                     if constexpr (WP) {
                         const int e = lane + 64 * m;
@@ -485,16 +494,19 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 const T hv = Gr::decode(hraw);
                 T acc = (T)0;
 #pragma unroll
-                for (int m = 0; m < Cfg::PM; ++m) acc += pv[m];
+                for (int m = 0; m < PMX; ++m) acc += pv[m];
                 tot = wave_sum(acc);
-                if constexpr (WP) hv_reg = (want_l || want_r) ? hv : (T)0;
+                if constexpr (RG) hv_reg = (want_l || want_r) ? hv : (T)0;
                 else {
                     if (lane < S) gh[0][lane] = want_l ? hv : (T)0;
                     if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = want_r ? hv : (T)0;
                 }
             } else {                       // one workgroup on this GPU (cluster launch): the ghosts come from level 2 only
-                if (lane < S) gh[0][lane] = (T)0;
-                if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = (T)0;
+                if constexpr (RG) hv_reg = (T)0;
+                else {
+                    if (lane < S) gh[0][lane] = (T)0;
+                    if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = (T)0;
+                }
             }
             if constexpr (MR) {
                 if (R > 1 && !fail) {
@@ -528,8 +540,12 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                     }
                     tot = partials_sum(lane < R ? XGr::decode(traw) : (T)0);     // rank order, the same tree on every GPU
                     const T xv = XGr::decode(xraw);
-                    if (xw_l) gh[0][lane] = xv;
-                    if (xw_r) gh[1][lane - 32] = xv;
+                    if constexpr (RG) {
+                        if (xw_l || xw_r) hv_reg = xv;
+                    } else {
+                        if (xw_l) gh[0][lane] = xv;
+                        if (xw_r) gh[1][lane - 32] = xv;
+                    }
                 }
             }
             if (fail) {
@@ -630,8 +646,11 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                     acc += (m < pm_count && lane + 64 * m < WT) ? XGr::decode(raw[m]) : (T)0;
                 const T hv = XGr::decode(hraw);
                 tot = wave_sum(acc);
-                if (lane < S) gh[0][lane] = want_l ? hv : (T)0;
-                if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = want_r ? hv : (T)0;
+                if constexpr (RG) hv_reg = (want_l || want_r) ? hv : (T)0;
+                else {
+                    if (lane < S) gh[0][lane] = want_l ? hv : (T)0;
+                    if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = want_r ? hv : (T)0;
+                }
                 if (fail && lane == 0) {
                     __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_abort = 1;
@@ -694,7 +713,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         if (multi) {
             T dummy;
             exchange(r, (T)0, dummy);
-            if constexpr (WP) {
+            if constexpr (RG) {
                 g_r = hv_reg;
                 if (g_lane) xs[1][gslot] = g_r;
             } else {
@@ -725,7 +744,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             if (q < n_ext_rows) xs[0][(xk + q / S + 1) * SP + q % S] = xst[1][q];
         }
         if (multi) {
-            if constexpr (WP) {
+            if constexpr (RG) {
                 g_p = hv_reg;
                 if (g_lane) xs[0][gslot] = g_p;
             } else {
@@ -763,7 +782,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 }
             }
             if (multi) {   // ghost r advances with the neighbours' upsilon blocks
-                if constexpr (WP) {
+                if constexpr (RG) {
                     g_r -= alpha * hv_reg;
                     if (g_lane) xs[1][gslot] = g_r;
                 } else {
@@ -799,7 +818,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 }
             }
             if (multi) {
-                if constexpr (WP) {
+                if constexpr (RG) {
                     g_p = hv_reg + beta * g_p;
                     if (g_lane) xs[0][gslot] = g_p;
                 } else {
@@ -1417,15 +1436,26 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
             return GATO_OK;
         }
     }
-    // launches of 2..32 workgroups: the wave-published form (its sweep is W << ceil(log2(waves)) granules: at most 4 loads per lane)
+    // Hand-off form of the plain and the cluster launches (option wave_pub, default 1): ghost blocks in registers always;
+    // per-wave published partials where a sweep - W << ceil(log2(waves)) granules - is at most 4 loads per lane (up to 32
+    // workgroups of 8 waves).  wave_pub = 0: the gathered form with the ghost blocks staged in LDS (also what the cycle-stamp
+    // build, DIAG = 1, runs).
     const int nw_ = a.threads / 64, wsh_ = nw_ <= 1 ? 0 : 32 - __builtin_clz((unsigned)(nw_ - 1));
-    const bool wp = !mr && !a.stamps && a.diag != 2 && a.batch <= 1 && a.wave_pub != 0 && a.groups > 1 && a.groups <= 32 &&
-                    nw_ * (int)(sizeof(T) / 4) <= 16 && (a.groups << wsh_) <= 256;
-    if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, false, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
-    else if (mr) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false, 0, false, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
-    else if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 1>), dim3(nblocks), dim3(a.threads), 0, st, a);
-    else if (a.diag == 2) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2>), dim3(nblocks), dim3(a.threads), 0, st, a);
-    else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false>), dim3(nblocks), dim3(a.threads), 0, st, a);
+    const bool rg = a.batch <= 1 && a.wave_pub != 0 && !a.stamps && (a.groups > 1 || mr);
+    const bool wp = rg && a.groups > 1 && nw_ * (int)(sizeof(T) / 4) <= 16 && (a.groups << wsh_) <= 256 && a.wave_pub != 3;
+    const dim3 grid(nblocks), block(a.threads);
+    if (mr) {
+        if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, true, 4>), grid, block, 0, st, a);
+        else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, true, -1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, true>), grid, block, 0, st, a);
+    } else if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 1>), grid, block, 0, st, a);
+    else if (a.diag == 2) {
+        if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2, 0, false, false, 4>), grid, block, 0, st, a);
+        else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2, 0, false, false, -1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2>), grid, block, 0, st, a);
+    } else if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, false, 4>), grid, block, 0, st, a);
+    else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, false, -1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false>), grid, block, 0, st, a);
     GATO_HIP_CHECK(hipGetLastError());
     if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
     return GATO_OK;

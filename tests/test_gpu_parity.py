@@ -1188,6 +1188,7 @@ def test_dz_in_the_pcg_epilogue_is_bit_identical_to_the_dz_launch(S, C, K, dt, B
     from gato_python_amd.solver import Solver
     s = system(S, C, K, seed=5) if K > 1 else synth.blocks_to_csr(*synth.make_blocks(S, C, 1, 5, False))
     res = {}
+    tol = 1e-9 if dt == np.float64 else 1e-5          # fp32: stop at convergence (60 iterations on 28 unknowns would run on rounding noise)
     for nofuse in (0, 1):
         sol = Solver(S, C, K, dt, batch=B)
         sol.set_option("no_fuse_dz", 1 if nofuse else -1)    # -1: also for one system (default: batches only)
@@ -1195,17 +1196,17 @@ def test_dz_in_the_pcg_epilogue_is_bit_identical_to_the_dz_launch(S, C, K, dt, B
         if B > 1:
             dev = sol.upload_batch([s] * B)
             lam, dz = sol.new(B * S * K), sol.new(B * sol.N)
-            sol.linsys_batched(*dev, 1e-9, 60, s.rho, lam, dz)
+            sol.linsys_batched(*dev, tol, 60, s.rho, lam, dz)
         else:
             dev = sol.upload_system(s)
             lam, dz = sol.new(S * K), sol.new(sol.N)
-            sol.linsys(*dev, 1e-9, 60, s.rho, lam, dz)
+            sol.linsys(*dev, tol, 60, s.rho, lam, dz)
         sol.check_status()
         assert sol.get_option("last_dz_fused") == (0 if nofuse else 1)
         res[nofuse] = (host(lam).copy(), host(dz).copy())
         sol.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     n_dz = (S + C) * K - C
-    # (14/7/2: 28 unknowns iterated 60 times in fp32, far past convergence - order-chaotic, tools/past_convergence.py)
-    check_solve(f"dz in the PCG epilogue {S}/{C}/{K} x{B}", s, S, C, K, dt, 1e-9, 60, res[0][0][:S * K], res[0][1][:n_dz], f64_tol=1e-9,
+    # (14/7/2 in fp32: a 28-unknown system whose last iterations run on rounding noise - order-chaotic, tools/past_convergence.py)
+    check_solve(f"dz in the PCG epilogue {S}/{C}/{K} x{B}", s, S, C, K, dt, tol, 60, res[0][0][:S * K], res[0][1][:n_dz], f64_tol=1e-9,
                 two_orders=K <= 2)
