@@ -143,7 +143,8 @@ struct gato_solver {
     unsigned pcg_epoch;        // next free hand-off epoch (resident kernels)
     int pcg_launch_id;
     size_t slots_bytes;
-    int asm_mode;       // option: 0 = auto, 1 = stage kernels one by one (convert / invert / schur / stair), 2 = fused launch
+    int asm_mode;       // option: 0 = auto, 1 = stage kernels one by one (convert / invert / schur / stair), 2 = fused launch (workgroup per knot), 3 = chunked launch
+    int asm_chunk;      // option: knots per workgroup of the chunked launch (0 = auto)
     int last_asm_fused, stamp_asm;
     double *eta_hist;   // eta after init and after every iteration (option record_eta), GATO_ETA_HIST_MAX + 1 entries
     int record_eta;
@@ -456,6 +457,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "pcg_threads")) s->pcg_threads = value;
     else if (!strcmp(name, "pcg_groups")) s->pcg_groups = value;
     else if (!strcmp(name, "asm_mode")) s->asm_mode = value;
+    else if (!strcmp(name, "asm_chunk")) s->asm_chunk = value;
     else if (!strcmp(name, "pcg_semi")) s->pcg_semi = value;
     else if (!strcmp(name, "pcg_epoch")) s->pcg_epoch = (unsigned)value;      // test hook: place the counter near its wrap
     else if (!strcmp(name, "stamp_asm")) s->stamp_asm = value;
@@ -985,9 +987,14 @@ static int assemble(gato_solver *s, int mode, const int *G_row, const int *G_col
     int rc;
     s->d.k_lo = s->d.k_hi = 0;              // whole solves work on every knot: the knot-range option is for the stage entries
     // the fused launch always forms the stair blocks: the other preconditioner modes take the stage kernels
-    const bool fused = s->precon_mode == GATO_PRECON_STAIR &&
-                       (s->asm_mode == 2 || (s->asm_mode == 0 && (long long)s->d.K * s->d.B <= 2ll * s->num_cus));   // one round of workgroups: measured crossover, DESIGN.md 3.3
-    s->last_asm_fused = fused;
+    const long long knots = (long long)s->d.K * s->d.B;
+    // option asm_mode: 0 auto (2 while one round of workgroups covers the solve, else 1 - measured crossover),
+    // 1 stage kernels, 2 one launch with a workgroup per knot (three-fold recomputation), 3 one launch with a workgroup per
+    // chunk of consecutive knots (everything between the stages stays in LDS)
+    const bool stair = s->precon_mode == GATO_PRECON_STAIR;
+    const bool chunked = stair && s->asm_mode == 3;          // measured equal to the stage kernels at best (gato_assembly.hip): opt-in
+    const bool fused = chunked || (stair && (s->asm_mode == 2 || (s->asm_mode == 0 && knots <= 2ll * s->num_cus)));
+    s->last_asm_fused = chunked ? 2 : fused;
     if (!fused) {
         if (mode == 0) {                 // CSR: the gather launch also inverts Q_k, R_k while they sit in LDS
             if (s->d.B > 1 && (s->d.nnzG <= 0 || s->d.nnzC <= 0)) return gato_convert(s, G_row, G_col, G_val, C_row, C_col, C_val, rho, s->G_dense, s->C_dense, st);
@@ -1014,6 +1021,19 @@ static int assemble(gato_solver *s, int mode, const int *G_row, const int *G_col
     a.rho = rho; a.g = d_g; a.c = d_c;
     a.Gd = s->G_dense; a.Cd = const_cast<void *>(C_dense); a.Ginv = s->Ginv; a.Sbd = s->Sbd; a.Pbd = s->Pbd; a.gamma = s->gamma;
     a.stamps = s->stamp_asm ? (unsigned long long *)s->sw.scalars + 8 : nullptr;
+    if (chunked) {
+        // knots per workgroup: a whole system where there are many (no halo knots at all); else enough chunks for ~2 workgroups
+        // per CU, at least 8 knots each (a chunk recomputes two halo knots)
+        int ch = s->asm_chunk > 0 ? s->asm_chunk : 0;
+        if (!ch) {
+            if (s->d.B >= 2 * s->num_cus || s->d.K <= 64) ch = s->d.K;
+            else {
+                const long long want = (knots + 2ll * s->num_cus - 1) / (2ll * s->num_cus);
+                ch = (int)(want < 8 ? 8 : want);
+            }
+        }
+        a.chunk = ch > s->d.K ? s->d.K : ch;
+    }
     return s->ops->assemble(s->d, a, st);
 }
 

@@ -249,6 +249,7 @@ struct AsmArgs {
     const void *g, *c;
     void *Gd, *Cd, *Ginv, *Sbd, *Pbd, *gamma;
     unsigned long long *stamps;      // diagnostic (option stamp_asm): one workgroup's phase boundaries, 100 MHz ticks
+    int chunk;                       // > 0: the chunked launch (assemble_chunk_kernel), this many consecutive knots per workgroup
 };
 template <typename T, int S, int C>
 int launch_assemble(const Dims &d, const AsmArgs &a, hipStream_t st);

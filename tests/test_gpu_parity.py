@@ -739,7 +739,10 @@ def test_fused_assembly_is_bit_identical_to_the_stage_kernels(S, C, K, seed, dq,
     s = system(S, C, K, seed, dq) if K > 1 else synth.blocks_to_csr(*synth.make_blocks(S, C, 1, seed, dq))
     names = ["G_dense", "C_dense", "Ginv", "S", "Pinv", "gamma", "lam", "dz"]
     ref = None
-    for opts in (dict(asm_mode=1), dict(asm_mode=2)):
+    # asm_mode 3: the chunked launch (a workgroup per chunk of consecutive knots, one wave per knot, everything between the
+    # stages in LDS) - one chunk for the whole system, chunks of 8 (halo knots re-derived at every chunk start), of 3 and of 1
+    for opts in (dict(asm_mode=1), dict(asm_mode=2), dict(asm_mode=3), dict(asm_mode=3, asm_chunk=8), dict(asm_mode=3, asm_chunk=3),
+                 dict(asm_mode=3, asm_chunk=1)):
         sol = make_solver(S, C, K, dt)
         for k, v in opts.items():
             sol.set_option(k, v)
@@ -748,7 +751,7 @@ def test_fused_assembly_is_bit_identical_to_the_stage_kernels(S, C, K, seed, dq,
             sol.linsys(*dev, 1e-8, 50, s.rho)
             sol.check_status()
         got = {n: sol.read_buffer(n) for n in names}
-        assert sol.get_option("last_asm_fused") == (1 if opts["asm_mode"] == 2 else 0)
+        assert sol.get_option("last_asm_fused") == {1: 0, 2: 1, 3: 2}[opts["asm_mode"]]
         sol.close()
         if ref is None:
             ref = got
@@ -764,9 +767,11 @@ def test_fused_assembly_batched_and_blocks(dt):
     names = ["G_dense", "Ginv", "S", "Pinv", "gamma", "lam", "dz"]
     from gato_python_amd.solver import Solver
     ref = None
-    for mode in (1, 2):
+    for mode in (1, 2, 3, 13):
         sol = Solver(S, C, K, dt, batch=B)
-        sol.set_option("asm_mode", mode)
+        sol.set_option("asm_mode", mode % 10)
+        if mode == 13:
+            sol.set_option("asm_chunk", 7)                     # chunks of 7 of 20 knots: halo knots in every system
         dev = sol.upload_batch(systems)
         lam, dz = sol.new(B * S * K), sol.new(B * sol.N)
         sol.linsys_batched(*dev, 1e-8, 60, systems[0].rho, lam, dz)
@@ -783,7 +788,7 @@ def test_fused_assembly_batched_and_blocks(dt):
     s = systems[0]
     Gd_o, Cd_o = co.convert(*s.csr_args()[:6], S, C, K, 0.0, dt)
     ref = None
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         sol = make_solver(S, C, K, dt)
         sol.set_option("asm_mode", mode)
         sol.linsys_blocks(sol.to_device(Gd_o), sol.to_device(Cd_o), sol.to_device(s.g), sol.to_device(s.c), 1e-8, 60, s.rho)
