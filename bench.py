@@ -48,6 +48,7 @@ WORKLOADS = {
     "iiwa_14_7_k16384_f32": (14, 7, 16384, np.float32, "K just beyond the register file (matrices 77 MB: L2 / Infinity Cache)"),
     # genuinely HBM-bound: matrices 1.2 GB > 256 MB Infinity Cache
     "iiwa_14_7_k131072_f32": (14, 7, 131072, np.float32, "K far beyond residency (HBM-roofline run)"),
+    "s32_c16_k32768_f32": (32, 16, 32768, np.float32, "configs[4]'s shape far beyond residency (S + Pinv 805 MB: HBM-bound)"),
 }
 MAX_ITERS = 100
 PCG_VARIANT = 0     # 1 = opt-in single-reduction (Chronopoulos-Gear) resident kernel, sweep entries only
@@ -479,6 +480,13 @@ def run_sweep(args, torch, emit):
     for mode, semi, tag in ((None, None, ""), (None, 1, "_semi"), (2, None, "_streaming")):
         r, _ = run_single("iiwa_14_7_k131072_f32", 3, 1, torch, pcg_mode=mode, pcg_reps=5, max_iters=20, pcg_semi=semi)
         annotate(r, "iiwa_14_7_k131072_f32" + tag)
+        r["workload"] += tag
+        r["max_iters"] = 20
+        emit(r)
+    # the same regime at configs[4]'s shape: LDS-DMA ring (auto) beside the semi-resident launch
+    for semi, tag in ((None, ""), (1, "_semi")):
+        r, _ = run_single("s32_c16_k32768_f32", 3, 1, torch, pcg_reps=5, max_iters=20, pcg_semi=semi)
+        annotate(r, "s32_c16_k32768_f32" + tag)
         r["workload"] += tag
         r["max_iters"] = 20
         emit(r)

@@ -657,13 +657,16 @@ static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int
         // the LDS-DMA ring (option pcg_semi = 3; auto: fp32 once S and Pinv together are well past the 256 MB Infinity Cache,
         // i.e. the re-read block rows come from HBM - measured cross-over at 14/7 fp32: K ~ 90 000 = 420 MB; below that the
         // semi-resident launch is served by the caches and wins, and in fp64 the ring's 4-row tiles are step-bound)
-        const bool dma_ok = !s->cl.on && !s->true_warm_start && kp <= s->ops->pcg_dma_max_knots();
-        const bool beyond_cache = s->esz == 4 && 2.0 * (double)s->d.bd() * (double)s->esz > 450e6;
+        // (K = the knots of THIS launch: a rank's shard in a cluster - what matters is what one GPU streams per product)
+        const bool dma_ok = !s->true_warm_start && s->ops->pcg_dma_max_knots() > 0 && kp <= s->ops->pcg_dma_max_knots();
+        // measured cross-overs against the semi-resident launch: 14/7 f32 K ~ 90 000 (420 MB of S + Pinv), 32/16 f32 K ~ 28 000
+        // (690 MB: its semi-resident launch already reads at 6 TB/s)
+        const bool beyond_cache = s->esz == 4 && 2.0 * 3.0 * S * S * (double)K * (double)s->esz > (S > 16 ? 700e6 : 450e6);
         int which = 0;
         if (s->pcg_semi == 1) which = semi_ok ? 1 : 0;
         else if (s->pcg_semi == 2) which = nores_ok ? 2 : 0;
         else if (s->pcg_semi == 3) which = dma_ok ? 3 : 0;
-        else which = (dma_ok && beyond_cache && K == s->d.K) ? 3 : semi_ok ? 1 : (nores_ok ? 2 : 0);
+        else which = (dma_ok && beyond_cache) ? 3 : semi_ok ? 1 : (nores_ok ? 2 : 0);
         if (!which) return 0;
         *groups = Wx; *threads = which == 1 ? xt : which == 2 ? nt : 512; *kpw = kp;
         s->plan_semi = which;
@@ -1597,6 +1600,6 @@ extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_P
     // the launches of a cluster wait for EACH OTHER: they are never queued behind one another (ranks sharing a device
     // exist in tests only), but they count for the other launches of this process
     int rc;
-    if ((rc = s->ops->pcg_resident(a, st))) return rc;
+    if ((rc = a.semi == 3 ? s->ops->pcg_dma(a, st) : s->ops->pcg_resident(a, st))) return rc;
     return gate_after(s->device, groups, st);
 }

@@ -23,38 +23,62 @@
 namespace gato {
 namespace {
 
+// largest divisor of n that is <= cap
+constexpr int largest_divisor_upto(int n, int cap)
+{
+    int best = 1;
+    for (int d = 1; d <= n && d <= cap; ++d)
+        if (n % d == 0) best = d;
+    return best;
+}
+
 template <typename T, int S>
 struct DmaCfg {
     static constexpr int VW = VecOf<T>::W;
     static constexpr int SP = pad_to(S, VW);
     static constexpr int ROW = 3 * S * S;                               // elements of one block row [left|main|right]
-    static constexpr int WL = 448;                                      // worker lanes: waves 1..7
-    // 37 632 B per tile at S = 14 in either type (fp32: 16 block rows, half the worker lanes have a row in a tile; fp64: 8
-    // block rows, a quarter), ring of three = 113 KB
-    static constexpr int TK = sizeof(T) == 4 ? 16 : 8;
+    // computing lanes (of the 448 lanes of waves 1..7, all of which move DMA pieces): a whole number of knots, chosen so
+    // that a round of them splits into tiles of ~37 KB - 448 = 32 knots at S = 14 (tiles of 16 / 8 block rows); at S = 32, 448
+    // = 14 knots would leave tiles of 2 block rows (24 KB: step-bound, 166 us per iteration at K = 32 768 against 137 semi-
+    // resident), 384 = 12 knots gives tiles of 3 (36 KB) and wave 7 only streams
+    static constexpr int WL = S == 32 ? 384 : 448;
+    static constexpr int KPR = WL / S;                                  // knots per round of computing lanes (S = 14: 32, S = 32: 12)
+    // Tile = TK whole block rows, TK a divisor of KPR (so that a tile is a whole number of the workers' rows and a round a
+    // whole number of tiles), as large as ~40 KB allow: 37 632 B at S = 14 in either type (fp32 16 block rows, fp64 8);
+    // 24 576 B at S = 32 (fp32 2 block rows, fp64 1).  Ring of three.
+    static constexpr int ROW_BYTES = ROW * (int)sizeof(T);
+    static constexpr int TK = largest_divisor_upto(KPR, 40 * 1024 / ROW_BYTES > 0 ? 40 * 1024 / ROW_BYTES : 1);
     static constexpr int TROWS = TK * S;
     static constexpr int SUBS = WL / TROWS;                             // tiles per round of worker lanes
-    static constexpr int KPR = WL / S;                                  // knots per round (32)
     static constexpr int NB = 3;
     static constexpr int TILE = TK * ROW;                               // elements
     static constexpr int TILE_BYTES = TILE * (int)sizeof(T);
     static constexpr int PIECES = (TILE_BYTES + 1023) / 1024;           // 1 KiB DMA pieces per tile
     static constexpr int NHI = (PIECES + 6) / 7, NLO = PIECES / 7;      // DMA instructions per tile of a worker wave: NHI or NLO
-    static constexpr int XR = sizeof(T) == 4 ? 16 : 8;                  // rounds = rows per worker lane (fp64: the operand window is twice the bytes)
-    static constexpr int MAXK = XR * KPR;                               // knots per workgroup (fp32 512: K <= 131 072 on 256 CUs; fp64 256)
-    static constexpr bool OK = WL % S == 0 && WL % TROWS == 0 && KPR % TK == 0 && 2 * S <= 64;
+    // rounds = rows per worker lane: by registers (r, p, lambda, y per row beside the 3S matrix entries of the row being
+    // multiplied) and by the LDS the operand window takes beside the ring
+    static constexpr int XR_REG = S <= 16 ? (sizeof(T) == 4 ? 16 : 8) : (sizeof(T) == 4 ? 12 : 4);   // S = 32 fp32: 241 VGPRs at 12 rows, spills at 16
+    static constexpr int XR_LDS = (150 * 1024 - NB * TILE_BYTES - 2 * SP * (int)sizeof(T)) / (KPR * SP * (int)sizeof(T));
+    static constexpr int XR = XR_REG < XR_LDS ? XR_REG : XR_LDS;
+    static constexpr int MAXK = XR * KPR;                               // knots per workgroup (S = 14: fp32 512 - K <= 131 072 on 256 CUs - fp64 256)
+    static constexpr bool OK = WL % S == 0 && WL <= 448 && KPR % TK == 0 && 2 * S <= 64 && S >= 8 && TILE_BYTES <= 48 * 1024 && XR >= 2 &&
+                               !(S > 16 && sizeof(T) == 8);              // fp64 at S = 32: 192 registers of matrix row alone - not built
 };
 
-template <typename T, int S>
+// MR: one rank of a cluster launch (gato_cluster_pcg) - the second hand-off level of pcg_resident_kernel<..., MR>: the rank's
+// total into every rank's mirror, its edge blocks into the neighbouring ranks' mirrors, polls on the own mirror only.
+template <typename T, int S, bool MR = false>
 __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
 {
     typedef DmaCfg<T, S> Cfg;
     typedef Granule<T> Gr;
+    typedef GranuleSys<T> XGr;
     constexpr int SP = Cfg::SP, GPV = Gr::GPV, XR = Cfg::XR, TK = Cfg::TK, ROW = Cfg::ROW, NB = Cfg::NB;
     constexpr int AHEAD = NB - 1;                                          // tiles in flight behind the one being multiplied
     static_assert((AHEAD - 1) * Cfg::NHI <= 63, "vmcnt is a 6-bit counter");
     constexpr int KPR = Cfg::KPR, SUBS = Cfg::SUBS, PM = 4;
     static_assert(Cfg::OK, "shape not supported by the DMA variant");
+    static_assert(SUBS * Cfg::TROWS == Cfg::WL && XR * SUBS >= 1, "a round of worker lanes is a whole number of tiles");
 
     __shared__ __attribute__((aligned(16))) T tiles[NB][Cfg::TILE];        // the ring
     __shared__ __attribute__((aligned(16))) T win[(Cfg::MAXK + 2) * SP];   // operand window of the current product
@@ -70,11 +94,16 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
     const int wl = tid - 64;                                               // worker lane
     const int wg = blockIdx.x, W = gridDim.x;
     const int K = a.K;
-    const int k0 = wg * a.knots_per_wg;
-    const int nk = min(a.knots_per_wg, K - k0);
-    const int jl = worker ? wl / S : 0, rr = worker ? wl - jl * S : 0;     // the lane's knot within a round, its row
+    const int k_begin = MR ? a.k_begin : 0, k_end = MR ? a.k_end : K;      // this launch's knot range (a rank's shard)
+    const int R = MR ? a.nranks : 1;
+    const int k0 = k_begin + wg * a.knots_per_wg;
+    const int nk = min(a.knots_per_wg, k_end - k0);
+    const bool cw = worker && wl < Cfg::WL;                                // computing lane (owns rows)
+    const int jl = cw ? wl / S : 0, rr = cw ? wl - jl * S : 0;             // the lane's knot within a round, its row
     const int NT = (nk + TK - 1) / TK;                                     // tiles per product
-    const bool has_left = k0 > 0, has_right = k0 + nk < K;
+    const bool has_left = k0 > 0, has_right = k0 + nk < K;                 // a neighbouring block row exists in the SYSTEM ...
+    const bool loc_left = MR ? wg > 0 : has_left, loc_right = MR ? wg < W - 1 : has_right;     // ... in a workgroup of this launch,
+    const bool x_left = MR && wg == 0 && has_left, x_right = MR && wg == W - 1 && has_right;   // or on the neighbouring GPU
 
     const T *__restrict__ dS = static_cast<const T *>(a.S_bd);
     const T *__restrict__ dP = static_cast<const T *>(a.P_bd);
@@ -85,6 +114,16 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
     gu64 *slots = (gu64 *)a.slots;
     gi32 *g_status = (gi32 *)a.status;
     const unsigned long long t_limit = a.timeout_ticks;
+    const int xslotG = pcg_xslot_granules(S, (int)sizeof(T));
+    const int xghL = 16 * GATO_MAX_RANKS, xghR = xghL + pcg_xghost_granules(S, (int)sizeof(T));
+    unsigned xepoch = MR ? a.xepoch0 : 0u;
+    gu64 *xp_prev = nullptr, *xp_next = nullptr;
+    __shared__ unsigned long long s_xpeer[MR ? GATO_MAX_RANKS : 1];
+    if constexpr (MR) {
+        if (a.rank > 0) xp_prev = (gu64 *)a.xpeer[a.rank - 1];
+        if (a.rank < R - 1) xp_next = (gu64 *)a.xpeer[a.rank + 1];
+        if (wave == 0 && lane < R) s_xpeer[lane] = (unsigned long long)a.xpeer[lane];
+    }
     if (tid == 0) s_abort = 0;
 
     // ---- state: r = gamma, lambda = 0 (gato_pcg.cuh:300-304) ----
@@ -92,7 +131,7 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
 #pragma unroll
     for (int e = 0; e < XR; ++e) {
         const int j = jl + KPR * e;
-        const bool on = worker && j < nk;
+        const bool on = cw && j < nk;
         r[e] = on ? dG[(size_t)(k0 + j) * S + rr] : (T)0;
         p[e] = (T)0; lam[e] = (T)0; y[e] = (T)0;
     }
@@ -114,7 +153,9 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
         const int kt = (int)t * TK;
         const int bytes = min(TK, nk - kt) * ROW * (int)sizeof(T);
         const char *src = (const char *)(M + (size_t)(k0 + kt) * ROW);
-        char *dst = (char *)&tiles[G % NB][0];
+        // LDS byte address of the slot: the ring's base (a constant: the local address of a __shared__ object) plus the slot
+        // offset - formed arithmetically, a generic -> local cast of a run-time pointer trips the compiler in the S = 32 build
+        const unsigned slot0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)&tiles[0][0] + (G % NB) * (unsigned)Cfg::TILE_BYTES;
         for (int q = wave - 1; q < Cfg::PIECES; q += 7) {
             const int off = q * 1024 + lane * 16;
             // Lanes past the end of a short last tile re-read the tile's first KiB (a block row is > 1 KiB) into the unused
@@ -125,8 +166,7 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
                 // inline asm: hipcc counts a builtin LDS-DMA against every later LDS read (s_waitcnt vmcnt(0) in front of the
                 // tile reads = no ring at all); an asm load is outside its bookkeeping, the counted waits below are ours
                 const char *gsrc = src + so;
-                const unsigned ldst = __builtin_amdgcn_readfirstlane(
-                    (unsigned)(size_t)(__attribute__((address_space(3))) char *)(dst + q * 1024));
+                const unsigned ldst = __builtin_amdgcn_readfirstlane(slot0 + (unsigned)q * 1024u);
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
@@ -146,7 +186,7 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
 #pragma unroll
         for (int e = 0; e < XR; ++e) {
             const int j = jl + KPR * e;
-            if (worker && j < nk) win[(j + 1) * SP + rr] = x[e];
+            if (cw && j < nk) win[(j + 1) * SP + rr] = x[e];
         }
         if (tid < S) win[tid] = ghost[which][0][tid];
         else if (tid < 2 * S) win[(nk + 1) * SP + (tid - S)] = ghost[which][1][tid - S];
@@ -167,13 +207,14 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
                 __syncthreads();
                 issue(G + AHEAD);
                 const int j = jl + KPR * e;
-                const bool mine = worker && wl >= sub * Cfg::TROWS && wl < (sub + 1) * Cfg::TROWS && j < nk;
+                const bool mine = cw && wl >= sub * Cfg::TROWS && wl < (sub + 1) * Cfg::TROWS && j < nk;
                 // all 3S entries of the row out of the tile first (independent LDS reads in flight together), then the FMAs
                 T m[3 * S];
                 if (mine) {
-                    const T *mrow = &tiles[G % NB][(jl % TK) * ROW + rr];
+                    const unsigned ts = G % NB;
+                    const int m0 = (jl % TK) * ROW + rr;
 #pragma unroll
-                    for (int c = 0; c < 3 * S; ++c) m[c] = mrow[c * S];
+                    for (int c = 0; c < 3 * S; ++c) m[c] = tiles[ts][m0 + c * S];
                 }
                 if (mine) {
                     const T *xw = &win[j * SP];
@@ -201,66 +242,111 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
 #pragma unroll
         for (int e = 0; e < XR; ++e) {
             const int j = jl + KPR * e;
-            if (worker && j < nk) {
+            if (cw && j < nk) {
                 if (j == 0) yedge[0][rr] = y[e];
                 if (j == nk - 1) yedge[1][rr] = y[e];
             }
         }
         __syncthreads();
+        if constexpr (MR) ++xepoch;
         if (wave == 0) {
             T tot = partials_total(wpart[epoch & 1], 8, lane);
             gu64 *mine = slots + ((size_t)(epoch & 1) * W + wg) * slotG;
-            if (lane < S) Gr::store(mine + 16 + lane * GPV, epoch, yedge[0][lane]);
-            else if (lane >= 32 && lane < 32 + S) Gr::store(mine + 16 + (S + lane - 32) * GPV, epoch, yedge[1][lane - 32]);
-            if (lane == 0) Gr::store(mine, epoch, tot);
-            gu64 *pbase = slots + (size_t)(epoch & 1) * W * slotG;
-            const bool want_l = has_left && lane < S;
-            const bool want_r = has_right && lane >= 32 && lane < 32 + S;
-            gu64 *hptr = want_l ? pbase + (size_t)(wg - 1) * slotG + 16 + (S + lane) * GPV
-                       : want_r ? pbase + (size_t)(wg + 1) * slotG + 16 + (lane - 32) * GPV
-                                : mine;
-            gu64 *pptr[PM];
-#pragma unroll
-            for (int m = 0; m < PM; ++m) pptr[m] = pbase + (size_t)min(lane + 64 * m, W - 1) * slotG;
-            const int pm_count = (W + 63) >> 6;
-            unsigned long long raw[PM][GPV], hraw[GPV];
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             bool fail = false;
-            if (W > 32) __builtin_amdgcn_s_sleep(12);
-            for (unsigned spin = 0;; ++spin) {
+            if constexpr (MR) {             // the rank's edge blocks go straight into the neighbouring GPU's mirror
+                if (x_left && lane < S) XGr::store(xp_prev + (size_t)(xepoch & 1) * xslotG + xghR + lane * GPV, xepoch, yedge[0][lane]);
+                if (x_right && lane >= 32 && lane < 32 + S)
+                    XGr::store(xp_next + (size_t)(xepoch & 1) * xslotG + xghL + (lane - 32) * GPV, xepoch, yedge[1][lane - 32]);
+            }
+            if (W > 1) {
+                if (lane < S) Gr::store(mine + 16 + lane * GPV, epoch, yedge[0][lane]);
+                else if (lane >= 32 && lane < 32 + S) Gr::store(mine + 16 + (S + lane - 32) * GPV, epoch, yedge[1][lane - 32]);
+                if (lane == 0) Gr::store(mine, epoch, tot);
+                gu64 *pbase = slots + (size_t)(epoch & 1) * W * slotG;
+                const bool want_l = loc_left && lane < S;
+                const bool want_r = loc_right && lane >= 32 && lane < 32 + S;
+                gu64 *hptr = want_l ? pbase + (size_t)(wg - 1) * slotG + 16 + (S + lane) * GPV
+                           : want_r ? pbase + (size_t)(wg + 1) * slotG + 16 + (lane - 32) * GPV
+                                    : mine;
+                gu64 *pptr[PM];
 #pragma unroll
-                for (int m = 0; m < PM; ++m) {
-                    if (m < pm_count) {
+                for (int m = 0; m < PM; ++m) pptr[m] = pbase + (size_t)min(lane + 64 * m, W - 1) * slotG;
+                const int pm_count = (W + 63) >> 6;
+                unsigned long long raw[PM][GPV], hraw[GPV];
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                if (W > 32) __builtin_amdgcn_s_sleep(12);
+                for (unsigned spin = 0;; ++spin) {
 #pragma unroll
-                        for (int g = 0; g < GPV; ++g) raw[m][g] = __hip_atomic_load(pptr[m] + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int m = 0; m < PM; ++m) {
+                        if (m < pm_count) {
+#pragma unroll
+                            for (int g = 0; g < GPV; ++g) raw[m][g] = __hip_atomic_load(pptr[m] + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < GPV; ++g) hraw[g] = __hip_atomic_load(hptr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bool ok = true;
+#pragma unroll
+                    for (int m = 0; m < PM; ++m) {
+                        if (m < pm_count) {
+#pragma unroll
+                            for (int g = 0; g < GPV; ++g) ok &= (unsigned)(raw[m][g] >> 32) == epoch;
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < GPV; ++g) ok &= (unsigned)(hraw[g] >> 32) == epoch;
+                    if (__all(ok)) break;
+                    if ((spin & 255u) == 255u) {
+                        const bool late = __builtin_amdgcn_s_memrealtime() - t0 > t_limit;
+                        const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
+                        if (late || other) { fail = true; break; }
                     }
                 }
+                T acc = (T)0;
 #pragma unroll
-                for (int g = 0; g < GPV; ++g) hraw[g] = __hip_atomic_load(hptr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bool ok = true;
+                for (int m = 0; m < PM; ++m) acc += (m < pm_count && lane + 64 * m < W) ? Gr::decode(raw[m]) : (T)0;
+                const T hv = Gr::decode(hraw);
+                tot = wave_sum(acc);
+                if (lane < S) gh[0][lane] = want_l ? hv : (T)0;
+                if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = want_r ? hv : (T)0;
+            } else {                       // one workgroup on this GPU (cluster launch): the ghosts come from level 2 only
+                if (lane < S) gh[0][lane] = (T)0;
+                if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = (T)0;
+            }
+            if constexpr (MR) {
+                if (R > 1 && !fail) {
+                    // level 2, across the GPUs of the node (pcg_resident_kernel<..., MR>): tot = this rank's total
+                    const size_t xo = (size_t)(xepoch & 1) * xslotG;
+                    if (wg == 0 && lane < R) XGr::store((gu64 *)s_xpeer[lane] + xo + a.rank * 16, xepoch, tot);
+                    gu64 *xl = (gu64 *)a.xslots + xo;                     // polls stay on THIS GPU's memory
+                    const bool xw_l = x_left && lane < S;
+                    const bool xw_r = x_right && lane >= 32 && lane < 32 + S;
+                    gu64 *tptr = xl + (size_t)min(lane, R - 1) * 16;
+                    gu64 *xhp = xw_l ? xl + xghL + lane * GPV : xw_r ? xl + xghR + (lane - 32) * GPV : tptr;
+                    unsigned long long traw[GPV], xraw[GPV];
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    for (unsigned spin = 0;; ++spin) {
 #pragma unroll
-                for (int m = 0; m < PM; ++m) {
-                    if (m < pm_count) {
+                        for (int g = 0; g < GPV; ++g) {
+                            traw[g] = __hip_atomic_load(tptr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            xraw[g] = __hip_atomic_load(xhp + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        bool ok = true;
 #pragma unroll
-                        for (int g = 0; g < GPV; ++g) ok &= (unsigned)(raw[m][g] >> 32) == epoch;
+                        for (int g = 0; g < GPV; ++g) ok &= (unsigned)(traw[g] >> 32) == xepoch && (unsigned)(xraw[g] >> 32) == xepoch;
+                        if (__all(ok)) break;
+                        if ((spin & 255u) == 255u) {
+                            const bool late = __builtin_amdgcn_s_memrealtime() - t0 > t_limit;
+                            const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
+                            if (late || other) { fail = true; break; }
+                        }
                     }
-                }
-#pragma unroll
-                for (int g = 0; g < GPV; ++g) ok &= (unsigned)(hraw[g] >> 32) == epoch;
-                if (__all(ok)) break;
-                if ((spin & 255u) == 255u) {
-                    const bool late = __builtin_amdgcn_s_memrealtime() - t0 > t_limit;
-                    const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
-                    if (late || other) { fail = true; break; }
+                    tot = partials_sum(lane < R ? XGr::decode(traw) : (T)0);     // rank order, the same tree on every GPU
+                    const T xv = XGr::decode(xraw);
+                    if (xw_l) gh[0][lane] = xv;
+                    if (xw_r) gh[1][lane - 32] = xv;
                 }
             }
-            T acc = (T)0;
-#pragma unroll
-            for (int m = 0; m < PM; ++m) acc += (m < pm_count && lane + 64 * m < W) ? Gr::decode(raw[m]) : (T)0;
-            const T hv = Gr::decode(hraw);
-            tot = wave_sum(acc);
-            if (lane < S) gh[0][lane] = want_l ? hv : (T)0;
-            if (lane >= 32 && lane < 32 + S) gh[1][lane - 32] = want_r ? hv : (T)0;
             if (fail && lane == 0) {
                 __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_abort = 1;
@@ -313,7 +399,7 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
 #pragma unroll
     for (int e = 0; e < XR; ++e) {
         const int j = jl + KPR * e;
-        if (worker && j < nk) dL[(size_t)(k0 + j) * S + rr] = lam[e];           // :433-435
+        if (cw && j < nk) dL[(size_t)(k0 + j) * S + rr] = lam[e];               // :433-435
     }
     if (wg == 0 && tid == 0) {
         a.iters[0] = aborted ? -1 : iters;
@@ -326,23 +412,33 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
 template <typename T, int S>
 int pcg_dma_max_knots()
 {
-    if constexpr (S == 14) return DmaCfg<T, S>::MAXK;
+    if constexpr (DmaCfg<T, S>::OK) return DmaCfg<T, S>::MAXK;
     else return 0;
 }
 
 template <typename T, int S>
-int launch_pcg_dma(const PcgLaunch &a, hipStream_t st)
+int launch_pcg_dma(const PcgLaunch &a0, hipStream_t st)
 {
-    if constexpr (S == 14) {
+    if constexpr (DmaCfg<T, S>::OK) {
         typedef DmaCfg<T, S> Cfg;
-        if (a.batch > 1 || a.lambda0 || a.groups < 2 || a.groups > 256 || a.threads != 512 || a.knots_per_wg > Cfg::MAXK ||
-            a.knots_per_wg < 1 || (long long)a.groups * a.knots_per_wg < a.K || (long long)(a.groups - 1) * a.knots_per_wg >= a.K ||
+        const bool mr = a0.xslots != nullptr;                   // one rank of a cluster launch
+        PcgLaunch a = a0;
+        if (!mr) { a.k_begin = 0; a.k_end = a.K; a.rank = 0; a.nranks = 1; }
+        const int Kl = a.k_end - a.k_begin;
+        if (mr && (a.nranks < 1 || a.nranks > GATO_MAX_RANKS || a.rank < 0 || a.rank >= a.nranks || a.k_begin < 0 || Kl < 1 || a.k_end > a.K ||
+                   (a.rank == 0) != (a.k_begin == 0) || (a.rank == a.nranks - 1) != (a.k_end == a.K) || a.flat)) {
+            set_error("pcg_dma(cluster): bad shard rank=%d/%d knots [%d,%d) of %d", a.rank, a.nranks, a.k_begin, a.k_end, a.K);
+            return GATO_EINVAL;
+        }
+        if (a.batch > 1 || a.lambda0 || a.groups < (mr ? 1 : 2) || a.groups > 256 || a.threads != 512 || a.knots_per_wg > Cfg::MAXK ||
+            a.knots_per_wg < 1 || (long long)a.groups * a.knots_per_wg < Kl || (long long)(a.groups - 1) * a.knots_per_wg >= Kl ||
             (reinterpret_cast<uintptr_t>(a.S_bd) & 15) || (reinterpret_cast<uintptr_t>(a.P_bd) & 15)) {
             set_error("pcg_dma: bad launch (K=%d groups=%d knots/wg=%d threads=%d)", a.K, a.groups, a.knots_per_wg, a.threads);
             return GATO_EINVAL;
         }
         if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-        hipLaunchKernelGGL((pcg_dma_kernel<T, S>), dim3(a.groups), dim3(512), 0, st, a);
+        if (mr) hipLaunchKernelGGL((pcg_dma_kernel<T, S, true>), dim3(a.groups), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((pcg_dma_kernel<T, S, false>), dim3(a.groups), dim3(512), 0, st, a);
         GATO_HIP_CHECK(hipGetLastError());
         if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
         return GATO_OK;

@@ -104,10 +104,12 @@ def test_cluster_back_to_back_solves_and_fixed_iterations():
         s_.close()
 
 
-def test_cluster_semi_resident_shards():
-    """Shards beyond the register file (semi-resident launch per rank) against the streaming kernels on one GPU."""
+@pytest.mark.parametrize("S,C,K,semi", [(14, 7, 30000, 1), (14, 7, 30000, 3), (32, 16, 9000, 3)])
+def test_cluster_semi_resident_shards(S, C, K, semi):
+    """Shards beyond the register file against the streaming kernels on one GPU: the semi-resident launch per rank (semi = 1)
+    and the LDS-DMA ring launch per rank (semi = 3: pcg_dma_kernel<..., MR>, what shards far beyond the caches get)."""
     from gato_python_amd.solver import Solver
-    S, C, K, R, dt = 14, 7, 30000, 2, np.float32
+    R, dt = 2, np.float32
     sysm = synth.make_system(S, C, K, seed=3)
     one = Solver(S, C, K, dt)
     d = one.upload_system(sysm)
@@ -119,8 +121,9 @@ def test_cluster_semi_resident_shards():
     sols = [Solver(S, C, K, dt) for _ in range(R)]
     for x in sols:
         x.set_option("max_workgroups", 120)               # the ranks share ONE GPU here: 2 x 120 workgroups fit its 256 CUs
+        x.set_option("pcg_semi", semi)
     lam, its = run_cluster_lockstep(sols, Sb, Pb, gam, 1e-4, 60)
-    assert sols[0].get_option("last_semi") == 1 and sols[0].get_option("last_groups") <= 120
+    assert sols[0].get_option("last_semi") == semi and sols[0].get_option("last_groups") <= 120
     assert len(set(its)) == 1 and abs(its[0] - int(it_s.cpu()[0])) <= 1, (its, it_s)
     # against the C oracle on the same (GPU-assembled) fp32 matrices, measured like every fp32 result
     hS, hP, hg = Sb.cpu().numpy(), Pb.cpu().numpy(), gam.cpu().numpy()

@@ -862,7 +862,8 @@ def test_kkt_producer_through_the_hip_path(K):
                                             (14, 7, 14000, np.float32, 2), (14, 7, 20011, np.float64, 2), (32, 16, 3001, np.float64, 2),
                                             (2, 1, 140000, np.float32, 2),
                                             (14, 7, 14000, np.float32, 3), (14, 7, 20011, np.float64, 3), (14, 7, 131072, np.float32, 3),
-                                            (14, 7, 13901, np.float32, 3), (14, 7, 65531, np.float64, 3)])
+                                            (14, 7, 13901, np.float32, 3), (14, 7, 65531, np.float64, 3),
+                                            (32, 16, 5003, np.float32, 3), (32, 16, 30011, np.float32, 3)])   # the ring at S = 32: 2-block-row tiles, 12 rows per lane
 def test_semi_resident_kernel_matches_the_streaming_kernels(S, C, K, dt, which):
     """K beyond the register file: one persistent launch whose workgroups keep part of their knots' matrix rows in
     registers and re-read the rest from memory every product (gato_pcg_resident.hip, XR > 0), against the streaming

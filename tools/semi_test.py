@@ -26,19 +26,20 @@ def run(S, C, K, dt, semi, iters=20, reps=5):
     sol.close()
     return out, res
 
-cases = [(14, 7, 14000, np.float32), (14, 7, 16384, np.float32), (14, 7, 32768, np.float32), (14, 7, 65536, np.float32), (14, 7, 131072, np.float32),
-         (14, 7, 16384, np.float64), (14, 7, 65536, np.float64), (32, 16, 8192, np.float32), (32, 16, 32768, np.float32),
-         (32, 16, 8192, np.float64)]
-if len(sys.argv) > 1:
-    cases = cases[:int(sys.argv[1])]
-for (S, C, K, dt) in cases:
-    b, lb = run(S, C, K, dt, 0)
-    line = f"{S}/{C}/{K} {np.dtype(dt).name}: streaming {b['us_per_iter']:.1f}"
-    for semi, name in ((1, "semi-resident"), (2, "no resident rows"), (3, "LDS-DMA ring")):
-        a, la = run(S, C, K, dt, semi)
-        if a["semi"] != semi:
-            line += f" | {name}: n/a"
-            continue
-        err = np.abs(la - lb).max() / np.abs(lb).max()
-        line += f" | {name} {a['groups']}x{a['threads']}: {a['us_per_iter']:.1f} us/iter (rel diff {err:.1e})"
-    print(line, flush=True)
+if __name__ == "__main__":
+    cases = [(14, 7, 14000, np.float32), (14, 7, 16384, np.float32), (14, 7, 32768, np.float32), (14, 7, 65536, np.float32), (14, 7, 131072, np.float32),
+             (14, 7, 16384, np.float64), (14, 7, 65536, np.float64), (32, 16, 8192, np.float32), (32, 16, 20480, np.float32), (32, 16, 32768, np.float32),
+             (32, 16, 40960, np.float32), (32, 16, 8192, np.float64)]
+    if len(sys.argv) > 1:
+        cases = [c for c in cases if str(c[0]) == sys.argv[1]] if sys.argv[1] in ("14", "32") else cases[:int(sys.argv[1])]
+    for (S, C, K, dt) in cases:
+        b, lb = run(S, C, K, dt, 0)
+        line = f"{S}/{C}/{K} {np.dtype(dt).name}: streaming {b['us_per_iter']:.1f}"
+        for semi, name in ((1, "semi-resident"), (2, "no resident rows"), (3, "LDS-DMA ring")):
+            a, la = run(S, C, K, dt, semi)
+            if a["semi"] != semi:
+                line += f" | {name}: n/a"
+                continue
+            err = np.abs(la - lb).max() / np.abs(lb).max()
+            line += f" | {name} {a['groups']}x{a['threads']}: {a['us_per_iter']:.1f} us/iter (rel diff {err:.1e})"
+        print(line, flush=True)
