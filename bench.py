@@ -408,7 +408,7 @@ def headline(res, name, steps, warmup, traffic, traffic_src, cpu=None, sweep_fil
     out = {
         "metric": "PCG iterations/s", "value": res["iters_per_s"], "unit": "iterations/s",
         "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": res["ms_per_step"],
-        "timed_steps": res["timed_steps"],      # blocks of exactly `steps` steps, repeated until 0.25 s of timed work
+        "timed_steps": res["timed_steps"],      # blocks of exactly `steps` steps, repeated until 1 s of timed work
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": res["dtype"], "data": "synthetic",
         "config": {"workload": name, "baseline_config": cfg, "STATE_SIZE": S, "CONTROL_SIZE": C, "KNOT_POINTS": K,
@@ -529,7 +529,7 @@ def main():
     torch.cuda.set_device(0)
     name = args.workload or "iiwa_14_7_k50_f64"
     S, C, K, dt, cfg = WORKLOADS[name]
-    res, sysm = run_single(name, args.steps, args.warmup, torch, args.pcg_mode, min_seconds=0.25)
+    res, sysm = run_single(name, args.steps, args.warmup, torch, args.pcg_mode, min_seconds=1.0)
     traffic, traffic_src = committed_traffic(name, res)
     cpu = None
     if not args.no_cpu:

@@ -9,7 +9,9 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-out = os.path.join(ROOT, "profiles")
+# GATO_PROFILE_OUT: summarise ON the GPU box into a directory under gpurun_out/ (the raw traces are far beyond what a
+# gpurun call copies back), then move the files into profiles/ here
+out = os.environ.get("GATO_PROFILE_OUT") or os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
 
 
@@ -37,10 +39,10 @@ if trace:
     with open(os.path.join(out, f"{tag}_pcg_launches.csv"), "w") as f:
         f.write("kernel,grid_threads,workgroup_threads,launches,avg_ns,min_ns,max_ns\n")
         for k, v in sorted(launch.items()):
-            # one-XCD launches (8x oversubscribed grid of the plain resident / single-reduction kernels): the first launch of a
-            # solver is preceded by 16 short calibration launches (16 iterations each, gato_capi.hip: calibrate_xcd) - listed apart
+            # one-XCD launches (8x oversubscribed grid of the plain resident / single-reduction kernels): creating a solver
+            # (gato_solver_create -> gato_solver_tune) runs 16 short trial launches (16 iterations each) - listed apart
             trials = []
-            packed = re.match(r"pcg_resident_kernel<\w+, \d+, \d+, 0, 0, 0, false, false>|pcg_cg1_kernel<", k[0]) and k[1] >= 16 * k[2]
+            packed = re.match(r"pcg_resident_kernel<\w+, \d+, \d+, 0, 0, 0, false, false(, -?\d+)?>|pcg_cg1_kernel<", k[0]) and k[1] >= 16 * k[2]
             if packed and len(v) > 16 and max(v) > 3 * min(v):
                 cut = max(v) / 3
                 short_ = [x for x in v if x < cut]
@@ -77,14 +79,16 @@ fetch, write = counter("fetch"), counter("write")
 WL = {"iiwa_14_7_k50_f64": ("pcg_single_f64m_kernel<14", 50), "iiwa_14_7_k50_f32": ("pcg_single_f32x2_kernel<14", 50),
       "iiwa_14_7_k512_f32": ("pcg_resident_kernel<float, 14", 512), "iiwa_14_7_k4096_f32": ("pcg_resident_kernel<float, 14", 4096),
       "iiwa_14_7_k4096_f64": ("pcg_resident_kernel<double, 14", 4096), "s32_c16_k1024_f32": ("pcg_resident_kernel<float, 32", 1024),
-      "iiwa_14_7_k131072_f32": ("pcg_dma_kernel<float, 14", 131072), "iiwa_14_7_k131072_f32_semi": ("pcg_resident_kernel<float, 14", 131072)}
+      "iiwa_14_7_k131072_f32": ("pcg_dma_kernel<float, 14", 131072), "iiwa_14_7_k131072_f32_semi": ("pcg_resident_kernel<float, 14", 131072),
+      "s32_c16_k32768_f32": ("pcg_dma_kernel<float, 32", 32768), "s32_c16_k32768_f32_semi": ("pcg_resident_kernel<float, 32", 32768)}
 bench = one(f"prof_{tag}_bench.json")
 geom = {}
 if bench:
     try:
-        d = json.loads(open(bench).read().strip().splitlines()[-1])
+        lines = [json.loads(x) for x in open(bench).read().strip().splitlines() if x.startswith("{")]
+        d = lines[-1]                           # the compact headline; the sweep entries are earlier lines
         geom[d["config"]["workload"]] = d["config"]["pcg_workgroups"] * d["config"]["pcg_threads"]
-        for r in d.get("sweep", []):
+        for r in [x["sweep_entry"] for x in lines if "sweep_entry" in x]:
             if "pcg_groups" in r and r.get("pcg_groups"):
                 geom[r["workload"]] = r["pcg_groups"] * r["pcg_threads"]
     except Exception as e:
@@ -153,7 +157,7 @@ if mf:
             f.write(f'"{k[0]}",{k[1]},{len(next(iter(v.values())))},' + ",".join(row) + "\n")
 # issue / LDS activity of the PCG kernels of the default workload
 rows = defaultdict(lambda: defaultdict(list))
-for kind in ("issue1", "issue2"):
+for kind in ("issue1", "issue2", "issue1_iiwa_14_7_k512_f32", "issue2_iiwa_14_7_k512_f32", "issue1_iiwa_14_7_k4096_f32", "issue2_iiwa_14_7_k4096_f32"):
     p = one(f"prof_{tag}_{kind}/*/*_counter_collection.csv")
     if p:
         for r in csv.DictReader(open(p)):
