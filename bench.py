@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - PCG iterations/s of the gato hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-sweep] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-sweep] [--no-cpu] [--sweep-out FILE]
 
 A step = one pass of the hot path over one synthetic KKT system already resident in HBM:
 CSR->dense scatter, Schur/preconditioner assembly, PCG with exit_tol = 0 (exactly max_iters = 100
@@ -12,10 +12,15 @@ recorded on the launch stream right around it: ALGORITHMIC bytes per iteration
 B_iter = [(6K-4) S^2 + 13 S K] w x iterations / launch time, against 8 TB/s.
 `cpu_baseline` = the C restatement of the same step (oracle/, "port") on the host cores.
 
+OUTPUT: the LAST stdout line is ONE compact strict-JSON object (< 4 KB: metric, value, config, roofline incl. traffic /
+limiter / latency_floor numbers, cpu_baseline, a one-record-per-entry sweep summary) - the line the driver parses.  Every
+sweep entry is printed in full on an EARLIER line ({"sweep_entry": ...}) as it finishes, and the whole sweep plus the method
+notes go to --sweep-out (default gpurun_out/bench_sweep.json).  A sweep entry that raises cannot take the headline down.
+
 N = 1 runs BASELINE.json configs[1] (IIWA 14/7, K = 50, fp64).  N > 1 (gato_python_amd/dist_bench.py): `value` is
 the same workload on every rank, each rank its own system - "replicas only", no data-path collective (one K = 50 system
-is a single workgroup and cannot shard) - and the knot-sharded solves that do exchange data ride along in the same
-line as "sharded" (configs[3]: K = 4096 split over the ranks) and "sharded_k262144_f32", each with its us/iteration
+is a single workgroup and cannot shard) - and the knot-sharded solves that do exchange data ride along in `config.sharded`
+of the same line (configs[3]: K = 4096 split over the ranks; configs[4]: 32/16/1024; K = 262144), each with its us/iteration
 beside the same system on one GPU and the transport it ran on (in-kernel xGMI peer stores, or the RCCL fallback).
 `--workload sharded_*` makes a sharded solve the line itself; `--workload batched_512x_f64` (any N) runs independent
 batches per rank (weak scaling, no collective).  `--gpus N` without a torch.distributed.run environment starts the N

@@ -734,6 +734,7 @@ static int calibrate_xcd(gato_solver *s, const PcgLaunch &a0, bool cg1, hipStrea
     t.dz = nullptr;
     t.lambda0 = nullptr;
     t.stamps = nullptr; t.diag = 0; t.ablate = 0;
+    t.timeout_ticks = 2000000ull;                       // 20 ms: a trial never waits the solver's 2 s
     t.ev_start = s->ev_cal0; t.ev_stop = s->ev_cal1;
     const unsigned need = 2u * (unsigned)t.max_iters + 8u;
     if (s->pcg_epoch > 0xFFFFFFFFu - 17u * need - 64u) {                    // counter about to wrap: start over on zeroed granules
@@ -754,11 +755,12 @@ static int calibrate_xcd(gato_solver *s, const PcgLaunch &a0, bool cg1, hipStrea
             if (rc == GATO_OK) rc = gate_after(s->device, s->num_cus, st);
             if (rc) return rc;
             GATO_HIP_CHECK(hipEventSynchronize(s->ev_cal1));
-            if (pass == 1) {
-                float ms = 0.f;
-                GATO_HIP_CHECK(hipEventElapsedTime(&ms, s->ev_cal0, s->ev_cal1));
-                if (sel == 0 || ms < best_ms) { best_ms = ms; *best = sel; }
-            }
+            float ms = 0.f;
+            GATO_HIP_CHECK(hipEventElapsedTime(&ms, s->ev_cal0, s->ev_cal1));
+            // a 16-iteration trial is ~50 us: one that took 10 ms sat in a hand-off (the CUs are shared with another process,
+            // its spin bound is the trial time-out) - give up, the launches run on XCD 0, instead of paying 16 time-outs
+            if (ms > 10.f) { *best = 0; return GATO_OK; }
+            if (pass == 1 && (sel == 0 || ms < best_ms)) { best_ms = ms; *best = sel; }
         }
     }
     *measured = true;

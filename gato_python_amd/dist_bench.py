@@ -339,6 +339,9 @@ RIDER_KEYS = ("value", "unit", "ms_per_step", "scaling", "dtype", "config", "pcg
 # the knot-sharded solves that ride along with the replicas line: configs[3] (K = 4096 over the ranks), configs[4]
 # (32/16/1024, "1 vs 8 GPUs") and the size where sharding can pay
 DEFAULT_RIDERS = ("sharded_k4096_f32", "sharded_s32_k1024_f32", "sharded_k262144_f32")
+# deadline of one rider's child job (a rider takes 5-15 s; three riders at their deadlines must stay well inside the few
+# minutes a caller gives the whole bench): 80 s, 120 s for the K = 262 144 one
+RIDER_DEADLINE_S = float(os.environ.get("GATO_RIDER_DEADLINE", "80"))
 LINE_LIMIT = 4096
 
 
@@ -409,6 +412,10 @@ def main(args):
         # riders: child jobs (see rider_in_child) unless asked otherwise; a rehearsal on one GPU with more than 3 ranks
         # would put more processes on the card than a box allows, so it keeps them in this process
         inproc = os.environ.get("GATO_BENCH_RIDERS_INPROC") == "1" or (ONE_GPU and world > 3)
+        if rank == 0:
+            # the replicas line NOW, before any rider starts: if the riders together outlast the caller's own limit, the last
+            # complete JSON line on stdout is still a valid headline (the final line below repeats it with the riders attached)
+            print(dumps_strict(out, LINE_LIMIT), flush=True)
         riders = {}
         for rider in DEFAULT_RIDERS:
             if rider == "sharded_k262144_f32" and world < 2:
@@ -416,7 +423,7 @@ def main(args):
             big = rider == "sharded_k262144_f32"
             st, wu = (3, 1) if big else (min(args.steps, 20), min(args.warmup, 3))
             if not inproc:
-                res = rider_in_child(dist, rank, world, rider, st, wu, 240 if big else 180)
+                res = rider_in_child(dist, rank, world, rider, st, wu, RIDER_DEADLINE_S * (1.5 if big else 1.0))
                 if rank == 0:
                     riders[rider] = res
                 continue
