@@ -103,25 +103,51 @@ __device__ __forceinline__ float quotient(float n, float d)
 }
 
 // y_row = [L M R]_row . window  - window read from LDS with 16-byte broadcast reads.
+// fp64: a row's 3S products are added left to right, the reference's order (gato_utils.cuh:177-183).
+// fp32 (GATO_PK_ROW, default on): packed FMAs - even and odd columns accumulate side by side in one v_pk_fma_f32 (the vector
+// units issue a packed FP32 FMA at the rate of a plain one: half the FMA instructions of a product) and meet in one final
+// add.  Another summation order than the reference's (columns 0,2,4,.. + columns 1,3,5,..); fp32 parity is measured against
+// the fp64 oracle beside the reference order's own error (tests/f32_parity.py).
+#ifndef GATO_PK_ROW
+#define GATO_PK_ROW 1
+#endif
 template <typename T, int S, int SP>
 __device__ __forceinline__ T row_times_window(const T (&m)[3 * S], const T *xw)
 {
     typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
     constexpr int NV = SP / VW;
-    T acc = (T)0;
+    if constexpr (sizeof(T) == 4 && GATO_PK_ROW && S % 2 == 0) {
+        typedef float F2 __attribute__((ext_vector_type(2)));
+        F2 acc = {0.f, 0.f};
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
+        for (int b = 0; b < 3; ++b) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            V v = *reinterpret_cast<const V *>(xw + b * SP + i * VW);
+            for (int i = 0; i < NV; ++i) {
+                const V v = *reinterpret_cast<const V *>(xw + b * SP + i * VW);
 #pragma unroll
-            for (int e = 0; e < VW; ++e) {
-                if (i * VW + e < S) acc = gato::fmaT(m[b * S + i * VW + e], v[e], acc);
+                for (int e = 0; e < VW; e += 2) {
+                    const int c = i * VW + e;                      // S even: a pair never straddles the end of a block
+                    if (c < S) acc = __builtin_elementwise_fma(F2{m[b * S + c], m[b * S + c + 1]}, F2{v[e], v[e + 1]}, acc);
+                }
             }
         }
+        return acc[0] + acc[1];
+    } else {
+        T acc = (T)0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                V v = *reinterpret_cast<const V *>(xw + b * SP + i * VW);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) {
+                    if (i * VW + e < S) acc = gato::fmaT(m[b * S + i * VW + e], v[e], acc);
+                }
+            }
+        }
+        return acc;
     }
-    return acc;
 }
 
 }  // namespace
