@@ -69,6 +69,11 @@ template <int SCOPE> struct GranuleT<double, SCOPE> {
     }
 };
 template <typename T> using Granule = GranuleT<T, __HIP_MEMORY_SCOPE_AGENT>;
+// workgroup-scope stores (global_store ... sc0): the granule stays in the XCD's write-back L2 instead of being written through
+// to memory.  Visible to agent-scope (sc1) loads of the SAME XCD only - 285 ns instead of 465 ns per one-way hand-off there
+// (tools/micro/pingpong.hip: "st sc0 / ld sc1" 569 ns per round trip against 929), never across XCDs (stale reads): used by
+// the one-XCD launches after they have CHECKED in the kernel that all their workgroups sit on one XCD.
+template <typename T> using GranuleXcd = GranuleT<T, __HIP_MEMORY_SCOPE_WORKGROUP>;
 template <typename T> using GranuleSys = GranuleT<T, __HIP_MEMORY_SCOPE_SYSTEM>;
 
 constexpr int pad_to(int x, int m) { return (x + m - 1) / m * m; }

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     constexpr bool STAMP = DIAG == 1, ABL = DIAG != 0;
     typedef ResidentCfg<T, S, MAXT> Cfg;
     typedef Granule<T> Gr;
+    typedef GranuleXcd<T> LGr;
     typedef GranuleSys<T> XGr;
     constexpr int SP = Cfg::SP;
     constexpr int GPV = Gr::GPV;
@@ -362,6 +363,15 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // lane's dot contribution.  On return: total in every thread; gh[][] = neighbours' boundary
     // blocks of `val` (zeros where there is no neighbour).
     const int abl = ABL ? a.ablate : 0;   // diagnostic timing-only switches, compiled out of the production build
+    // One-XCD launches (xcd_pack): once the workgroups have verified - below, with agent-scope granules - that they really all
+    // sit on ONE XCD, the hand-off granules are stored with WORKGROUP scope: they stay in that XCD's L2 (its CUs' sc1 loads see
+    // them there) instead of being written through to memory.  A placement that is not what the launch hoped for (the
+    // dispatcher is free to place blocks anywhere) just keeps the agent-scope stores.
+    bool fast_st = false;
+    auto gstore = [&](gu64 *g, unsigned ep, T v) {
+        if (fast_st) LGr::store(g, ep, v);
+        else Gr::store(g, ep, v);
+    };
     // WP: the ghost blocks of r and p and the boundary entry just gathered, in the polling lanes' registers
     T hv_reg = (T)0, g_r = g_r_init, g_p = (T)0;
     const bool g_lane = RG && wave == 0 && (lane < S || (lane >= 32 && lane < 32 + S));
@@ -370,17 +380,18 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         ++epoch;
         if constexpr (MR) ++xepoch;
         if (abl & 4) { total = (T)1 + prod * (T)1e-30; return; }
+        if (aborted) { total = (T)0; return; }             // the placement round below already timed out: no second wait
         T *wp = wpart[epoch & 1];
         gu64 *mine = slots + ((size_t)(epoch & 1) * W + wg) * slotG;
         if constexpr (WP) {
             if (W > 1) {
                 const T ws = wave_sum(prod);
-                if (lane == 0) Gr::store(mine + wave * GPV, epoch, ws);
+                if (lane == 0) gstore(mine + wave * GPV, epoch, ws);
             } else partials_store(wp, wave, lane, prod);      // one workgroup per rank (cluster): its total comes from LDS
         } else partials_store(wp, wave, lane, prod);
         if (!NR && W > 1 && active) {
-            if (j == 0) Gr::store(mine + 16 + r_ * GPV, epoch, val);
-            if (j == nk - 1) Gr::store(mine + 16 + (S + r_) * GPV, epoch, val);
+            if (j == 0) gstore(mine + 16 + r_ * GPV, epoch, val);
+            if (j == nk - 1) gstore(mine + 16 + (S + r_) * GPV, epoch, val);
         }
         if constexpr (MR && !NR) {          // the rank's edge blocks go straight into the neighbouring GPU's mirror
             if (active) {
@@ -391,8 +402,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         if (!WP || W == 1) __syncthreads();                                    // B1
         if constexpr (NR) {                 // boundary blocks of the vector just formed: from the product array (complete after B1)
             if (W > 1) {
-                if (tid < S) Gr::store(mine + 16 + tid * GPV, epoch, xst[1][tid]);
-                else if (tid < 2 * S) Gr::store(mine + 16 + tid * GPV, epoch, xst[1][(nk - 1) * S + (tid - S)]);
+                if (tid < S) gstore(mine + 16 + tid * GPV, epoch, xst[1][tid]);
+                else if (tid < 2 * S) gstore(mine + 16 + tid * GPV, epoch, xst[1][(nk - 1) * S + (tid - S)]);
             }
             if constexpr (MR) {
                 if (x_left && tid < S) XGr::store(xp_prev + (size_t)(xepoch & 1) * xslotG + xghR + tid * GPV, xepoch, xst[1][tid]);
@@ -413,7 +424,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             bool fail = false;
             if (W > 1) {
                 if constexpr (!WP) {
-                    if (lane == 0) Gr::store(mine, epoch, tot);
+                    if (lane == 0) gstore(mine, epoch, tot);
                 }
                 // sweep: partials of all workgroups + neighbours' halo blocks.  Every lane issues ALL its loads
                 // back to back from clamped (always valid) addresses and waits once: predicated loads would each
@@ -668,6 +679,43 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         else allreduce_and_halo(val, prod, total);
     };
 
+    // ---- one-XCD launches: are we really on one XCD?  One extra all-to-all round (agent scope) with the XCC id as payload;
+    // every workgroup reads the same W ids, so all take the same decision.  ~0.7 us once per launch.
+    if (!MR && X > 0 && W > 1 && W <= 64 && !(abl & 4)) {
+        __shared__ int s_same;
+        ++epoch;
+        if (wave == 0) {
+            unsigned id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+            id &= 0xfu;
+            gu64 *pb = slots + (size_t)(epoch & 1) * W * slotG;
+            if (lane == 0) __hip_atomic_store(pb + (size_t)wg * slotG, ((unsigned long long)epoch << 32) | id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gu64 *pp = pb + (size_t)min(lane, W - 1) * slotG;
+            unsigned long long raw = 0;
+            bool fail = false;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (unsigned spin = 0;; ++spin) {
+                raw = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((unsigned)(raw >> 32) == epoch)) break;
+                if ((spin & 255u) == 255u) {
+                    const bool late = __builtin_amdgcn_s_memrealtime() - t0 > t_limit;
+                    const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
+                    if (late || other) { fail = true; break; }
+                }
+            }
+            const bool same = !fail && __all((unsigned)raw == id);
+            if (lane == 0) {
+                s_same = same ? 1 : 0;
+                if (fail) {
+                    __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_abort = 1;
+                }
+            }
+        }
+        __syncthreads();
+        fast_st = s_same != 0;
+        aborted = s_abort != 0;
+    }
     // ---- r~ = Pinv r ; p = r~ ; eta = r . r~   (gato_pcg.cuh:316-335) ------------------------
     auto pinv_times = [&](const T *xw) -> T {
         if constexpr (NR) return (T)0;

@@ -553,7 +553,9 @@ def test_one_xcd_placement_is_a_hint_only():
     S, C, K = 14, 7, 512
     s = synth.make_system(S, C, K, seed=5)
     ref = None
-    for opts in ({}, dict(xcd_sel=5), dict(xcd_sel=2), dict(xcd_pack=0)):
+    # xcd_pack = 2, 3: the working blocks are dealt to two / three XCDs - the in-kernel placement check then finds different XCC
+    # ids and keeps the agent-scope stores (the workgroup-scope stores of the one-XCD fast path would never be seen there)
+    for opts in ({}, dict(xcd_sel=5), dict(xcd_sel=2), dict(xcd_pack=0), dict(xcd_pack=2), dict(xcd_pack=3)):
         sol = make_solver(S, C, K, np.float32)
         for k, v in opts.items():
             sol.set_option(k, v)
@@ -567,6 +569,8 @@ def test_one_xcd_placement_is_a_hint_only():
             assert sel == opts["xcd_sel"]
         elif opts.get("xcd_pack") == 0:
             assert sel == -1
+        elif "xcd_pack" in opts:
+            assert 0 <= sel <= 7
         else:
             assert 0 <= sel <= 7
         if ref is None:
