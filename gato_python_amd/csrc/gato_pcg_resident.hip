@@ -462,7 +462,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 // Cross-XCD launches: the first poll can never hit (the publishers' stores need a fabric round
                 // trip), and W*W early loads only queue in front of those stores.  ~0.35 us of sleep before the
                 // first poll measured -5..-10 % per iteration for W > 32 and +6 % for one-XCD launches.
-                if (W > 32) __builtin_amdgcn_s_sleep(12);
+                if (W > 64) __builtin_amdgcn_s_sleep(12);
+                else if (W > 32) __builtin_amdgcn_s_sleep(10);      // round 3 sweep: 32/16/1024 (W = 64) 10: 4.22 / 12: 4.32 us, 14/7/2048 (W = 57) 3.51 / 3.61
                 for (unsigned spin = 0;; ++spin) {
 #pragma unroll
                     for (int m = 0; m < PMX; ++m) {

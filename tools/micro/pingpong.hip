@@ -55,10 +55,19 @@ __global__ void pingpong(u64 *slots, int partner_block, int rounds, u64 *out, in
     out[me * 2 + 1] = (u64)ok;
 }
 
+// memory kind of the slots: 0 = hipMalloc (default), 1 = uncached device memory, 2 = fine-grained (the kinds of the cluster mirrors)
+static int g_mem_kind = 0;
+static void alloc_slots(u64 **p, size_t bytes)
+{
+    if (g_mem_kind == 1) hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocUncached);
+    else if (g_mem_kind == 2) hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocFinegrained);
+    else hipMalloc(p, bytes);
+}
+
 template <int V> void run(const char *name, int partner)
 {
     u64 *slots, *out; int *xcc;
-    hipMalloc(&slots, 4096); hipMemset(slots, 0, 4096);
+    alloc_slots(&slots, 4096); hipMemset(slots, 0, 4096);
     hipMalloc(&out, 64); hipMemset(out, 0, 64);
     hipMalloc(&xcc, 16);
     const int rounds = 5000;
@@ -101,7 +110,7 @@ __global__ void allgather(u64 *slots, int W, int pack, int rounds, int with_barr
 void run_allgather(int W, int pack, int threads, int with_barrier)
 {
     u64 *slots, *out;
-    hipMalloc(&slots, 2 * 64 * 256 + 4096); hipMemset(slots, 0, 2 * 64 * 256 + 4096);
+    alloc_slots(&slots, 2 * 64 * 256 + 4096); hipMemset(slots, 0, 2 * 64 * 256 + 4096);
     hipMalloc(&out, 64); hipMemset(out, 0, 64);
     const int rounds = 20000;
     hipLaunchKernelGGL(allgather, dim3(pack ? 8 * W : W), dim3(threads), 0, 0, slots, W, pack, rounds, with_barrier, out);
@@ -117,6 +126,7 @@ template <int V> void both(const char *name) { run<V>(name, 8); run<V>(name, 1);
 
 int main(int argc, char **argv)
 {
+    if (const char *mk = getenv("PINGPONG_MEM")) { g_mem_kind = atoi(mk); printf("slots in memory kind %d (0 hipMalloc, 1 uncached, 2 fine-grained)\n", g_mem_kind); }
     if (argc > 1) {
         for (int W : {2, 4, 15, 29, 32})
             for (int pack : {1, 0}) {
