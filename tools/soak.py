@@ -10,7 +10,8 @@ from gato_python_amd.solver import Solver
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 bad = 0
-for (S, C, K, dt, opts) in [(14, 7, 512, np.float32, {}), (14, 7, 4096, np.float32, {}), (14, 7, 4096, np.float64, {}),
+for (S, C, K, dt, opts) in [(14, 7, 512, np.float32, {}), (14, 7, 1024, np.float32, {}), (14, 7, 512, np.float64, {}),   # one XCD: workgroup-scope granules
+                            (14, 7, 512, np.float32, dict(xcd_pack=2)), (14, 7, 4096, np.float32, {}), (14, 7, 4096, np.float64, {}),
                             (32, 16, 1024, np.float32, {}), (14, 7, 4096, np.float32, dict(pcg_variant=1)),
                             (14, 7, 700, np.float64, dict(pcg_threads=256)), (14, 7, 50, np.float64, {}),
                             (14, 7, 20000, np.float32, {}), (14, 7, 15000, np.float64, {})]:     # semi-resident launches
