@@ -50,7 +50,7 @@ static Ops make_ops(int dtype)
         return launch_compute_dz<T, S, C>(d, (const T *)Gi, (const T *)Cd, (const T *)g, (const T *)lam, (T *)dz, st);
     };
     o.pcg_plan = [](PcgPlan *p) { return pcg_resident_plan<T, S>(p); };
-    o.pcg_resident = [](const PcgLaunch &a, hipStream_t st) { return launch_pcg_resident<T, S>(a, st); };
+    o.pcg_resident = [](const PcgLaunch &a, hipStream_t st) { return launch_pcg_resident<T, S>(a, st); };   // incl. the DPP-row layout
     o.pcg_dma_max_knots = []() { return pcg_dma_max_knots<T, S>(); };
     o.pcg_dma = [](const PcgLaunch &a, hipStream_t st) { return launch_pcg_dma<T, S>(a, st); };
     o.pcg_cg1_max_threads = []() { return pcg_cg1_max_threads<T, S>(); };
@@ -140,6 +140,7 @@ struct gato_solver {
     } sh;
     char *ghosts;   // [r|p][ping-pong][left|right][S]
     int plan_semi, pcg_semi;   // semi-resident launch planned / option (-1 auto, 0 off)
+    int plan_dpp, dpp_rows;    // DPP-row layout planned / option (-1 auto, 0 never, 1 wherever a plain launch fits)
     unsigned pcg_epoch;        // next free hand-off epoch (resident kernels)
     int pcg_launch_id;
     size_t slots_bytes;
@@ -362,6 +363,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     s->xcd_pack = -1;
     s->xcd_sel = -1;
     s->wave_pub = 1;
+    s->dpp_rows = -1;
     s->pcg_semi = -1;
     s->timeout_ms = 2000;
     s->cluster_flat = 1;
@@ -466,6 +468,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "no_single_lds")) s->no_single_lds = value;
     else if (!strcmp(name, "no_pair")) s->no_pair = value;
     else if (!strcmp(name, "wave_pub")) s->wave_pub = value;
+    else if (!strcmp(name, "dpp_rows")) s->dpp_rows = value;
     else if (!strcmp(name, "pcg_variant")) s->pcg_variant = value;
     else if (!strcmp(name, "record_eta")) s->record_eta = value;
     else if (!strcmp(name, "xcd_pack")) s->xcd_pack = value;
@@ -529,6 +532,7 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "last_threads")) *value = s->last_threads;
     else if (!strcmp(name, "last_mode")) *value = s->last_mode;
     else if (!strcmp(name, "last_pair")) *value = s->plan_pair;
+    else if (!strcmp(name, "last_dpp")) *value = s->plan_dpp;
     else if (!strcmp(name, "last_xcd_sel")) *value = s->last_xcd_sel;
     else if (!strcmp(name, "last_variant")) *value = s->last_variant;
     else if (!strcmp(name, "asm_mode")) *value = s->asm_mode;
@@ -584,6 +588,42 @@ static int plan_resident(gato_solver *s, int *groups, int *threads, int *kpw)
     return plan_resident_k(s, s->d.K, groups, threads, kpw);
 }
 
+// Geometry of a plain launch in the DPP-row layout (L lanes per knot); 0 if K does not fit max_wg such workgroups.
+static int plan_dpp_rows(gato_solver *s, int K, int L, int max_wg, int *groups, int *threads, int *kpw)
+{
+    const int maxT = s->plan.max_threads;
+    int t = s->pcg_threads, g = s->pcg_groups;
+    if (t > 0) {
+        t = (t + 63) / 64 * 64;
+        if (t > maxT) t = maxT;
+        if (t < 64) t = 64;
+    }
+    if (g > 0 && t == 0) {
+        const int k_per = (K + g - 1) / g;
+        t = (k_per * L + 63) / 64 * 64;
+        if (t > maxT) return 0;
+    }
+    if (t == 0) {
+        if (K * L <= maxT) t = (K * L + 63) / 64 * 64;
+        else {
+            t = maxT < 512 ? maxT : 512;
+            while (t < maxT && (K + (t / L) - 1) / (t / L) > max_wg) t += 64;
+            if ((K + (t / L) - 1) / (t / L) > 32 && (K + (maxT / L) - 1) / (maxT / L) <= 32) {      // one XCD if larger workgroups get there
+                while (t < maxT && (K + (t / L) - 1) / (t / L) > 32) t += 64;
+            }
+        }
+    }
+    const int k_per_max = t / L;
+    if (k_per_max < 1) return 0;
+    int W = (K + k_per_max - 1) / k_per_max;
+    if (g > 0 && g >= W) W = g;
+    if (W > max_wg) return 0;
+    const int k_per = (K + W - 1) / W;
+    W = (K + k_per - 1) / k_per;
+    *groups = W; *threads = t; *kpw = k_per;
+    return 1;
+}
+
 // K = knots the launch works on (the system's, or one rank's shard of it)
 static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int *kpw)
 {
@@ -594,6 +634,26 @@ static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int
     int g = s->pcg_groups;
     const int maxT = s->plan.max_threads;
     s->plan_semi = 0;
+    s->plan_dpp = 0;
+    // DPP-row layout of the plain / cluster launches (option dpp_rows: -1 auto, 0 never, 1 wherever such a launch fits): auto
+    // leaves the one-workgroup special kernels (two rows per lane) and one-workgroup-per-system batches alone
+    if (s->plan.dpp_lanes > 0 && s->dpp_rows != 0 && s->stamp_pcg != 1) {
+        const int L = s->plan.dpp_lanes;
+        const bool one_wg_kernel = t == 0 && g <= 1 &&
+            ((!s->no_pair && s->plan.pair_threads > 0 && K * (S / 2) <= s->plan.pair_threads) ||
+             (!s->no_pair && !s->no_single_lds && s->plan.mixed_rows > 0 && K * S <= s->plan.mixed_rows && K * S > maxT && !s->cl.on && K == s->d.K) ||
+             (K * S > maxT && K * S <= s->plan.single_max_threads && !s->no_single_lds));
+        const bool batch_split = s->d.B > 1 && K * L > maxT && K * S <= maxT;          // a batch needs one workgroup per system
+        // measured (tools/dpp_ab.py, same box): fp64 -7..-21 % per iteration at S = 12 / 14 / 32, fp32 -7..-14 % at S = 32; fp32 at
+        // S <= 16 gains nothing (its packed-FMA products are not LDS bound) and loses lanes to the idle rows (14/7/4096: 128
+        // workgroups instead of 114, +1 %)
+        const bool pays = s->esz == 8 || S > 16;
+        if ((s->dpp_rows > 0 || (pays && !one_wg_kernel && !batch_split)) && plan_dpp_rows(s, K, L, max_wg, groups, threads, kpw)) {
+            s->plan_pair = 0;
+            s->plan_dpp = 1;
+            return 1;
+        }
+    }
     if (t > 0) {
         t = (t + 63) / 64 * 64;
         if (t > maxT) t = maxT;
@@ -791,6 +851,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.batch = batch;
         a.pair = s->plan_pair;
         a.semi = cg1 ? 0 : s->plan_semi;
+        a.dpp_rows = cg1 ? 0 : s->plan_dpp;
         // option xcd_pack: -1 = auto (default): up to 32 workgroups are placed on ONE XCD (measured 15-20 % faster hand-offs:
         // 14/7/512 f32 3.96 -> 3.11 us/iteration); spreading over 2..7 XCDs measured no better than the plain grid, so
         // auto leaves larger launches alone.  0 = off, 1..7 = force that many XCDs (tools/xcd_pack_test.py).
@@ -847,7 +908,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         if (a.xcd_pack > 0) {
             if (s->xcd_sel >= 0) a.xcd_sel = s->xcd_sel;
             else {
-                const long long key = ((long long)groups << 32) | ((long long)threads << 8) | (cg1 ? 2 : 0) | (s->esz == 8 ? 1 : 0) | 4;
+                const long long key = ((long long)groups << 32) | ((long long)threads << 8) | (cg1 ? 2 : 0) | (s->esz == 8 ? 1 : 0) | 4 | (a.dpp_rows ? 8 : 0);
                 if (s->tuning) {
                     // gato_solver_tune: the trial launches (scratch outputs, own events); no launch of the caller's follows
                     bool measured = false;
@@ -1563,7 +1624,7 @@ extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_P
     a.S_bd = d_S; a.P_bd = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda;
     a.lambda0 = s->true_warm_start ? d_lambda : nullptr;
     a.K = s->d.K; a.max_iters = max_iters; a.exit_tol = exit_tol;
-    a.batch = 1; a.semi = s->plan_semi;
+    a.batch = 1; a.semi = s->plan_semi; a.dpp_rows = s->plan_dpp;
     a.wave_pub = s->wave_pub;
     a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
     a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;

@@ -163,6 +163,7 @@ struct PcgLaunch {
     int knots_per_wg;            // contiguous knots owned by each workgroup (last may own fewer)
     int groups;                  // W = gridDim.x
     int threads;                 // blockDim.x (multiple of 64, >= knots_per_wg * S unless semi)
+    int dpp_rows;                // 1: DPP-row layout (a knot owns whole 16-lane rows; threads >= knots_per_wg * 16 or 32), plain and cluster launches
     int semi;                    // 1: semi-resident launch (knots_per_wg exceeds the lanes, the rest are extra rows); 2: no resident rows; 3: LDS-DMA ring (gato_pcg_dma.hip)
     unsigned long long *slots;   // hand-off granules: every 8-byte word {epoch, payload}; epochs only grow, so no re-zeroing
     unsigned epoch0;             // this launch uses epochs epoch0+1 .. (the solver hands out disjoint ranges)
@@ -228,6 +229,7 @@ struct PcgPlan {
     int semi_rows;            // ... and the extra rows a lane can take
     int nores_threads;        // > 0: variant without resident rows: workgroup size ...
     int nores_rows;           // ... and rows per lane
+    int dpp_lanes;            // > 0: the plain and cluster launches exist in the DPP-row layout, with this many lanes per knot
 };
 
 // Per-(dtype, S, C) kernel launchers, defined in the .hip files and instantiated for GATO_SHAPES.
@@ -265,6 +267,8 @@ template <typename T, int S>
 int pcg_resident_plan(PcgPlan *plan);
 template <typename T, int S>
 int launch_pcg_resident(const PcgLaunch &a, hipStream_t st);
+template <typename T, int S>
+int launch_pcg_resident_dpp(const PcgLaunch &a, hipStream_t st);      // gato_pcg_resident_dpp.hip; called by launch_pcg_resident
 template <typename T, int S> int pcg_dma_max_knots();          // knots per workgroup of the LDS-DMA variant (0: none for this shape)
 template <typename T, int S>
 int launch_pcg_dma(const PcgLaunch &a, hipStream_t st);

@@ -155,5 +155,80 @@ __device__ __forceinline__ T row_times_window(const T (&m)[3 * S], const T *xw)
     }
 }
 
+
+// ---- row products with the operand window in REGISTERS (DPP-row layout, template parameter DR of pcg_resident_kernel) -----
+// Layout: a knot owns whole 16-lane DPP rows (S <= 16: one row, lanes S..15 idle; 16 < S <= 32: two rows), so the entries of
+// a knot's block of the operand vector sit in the lanes of that row and `v_fmac_f64_dpp / v_fmac_f32_dpp ... row_newbcast:c`
+// (gfx90a+: lane c of each row feeds all 16 lanes of the row) reads them straight from the neighbouring lanes' registers: a
+// product costs 2 scalar LDS reads per lane (the two neighbouring knots' entries of the lane's row index) instead of 3S/VW
+// 16-byte reads, which is what bounds the LDS-window form (tools/micro/dppfma.hip: fp64 14-row knots 268 ns against 504 ns
+// per product on 8 waves).  Same per-row summation order as row_times_window: fp64 left to right (the reference's,
+// gato_utils.cuh:177-183), fp32 even columns + odd columns - bit-identical results.
+// The chains are single asm statements: the compiler knows no DPP hazards inside inline asm (a VALU write of the DPP
+// source needs 2 wait states, a VALU write of EXEC 5), so every statement starts with its own s_nop.
+template <int S> struct DppRows {
+    static constexpr bool ok = S == 12 || S == 14 || S == 16 || S == 32;      // block widths with a chain below
+    static constexpr int lanes = S <= 16 ? 16 : 32;                            // lanes per knot
+};
+#define GATO_FM64(c, op) "v_fmac_f64_dpp %0, %1, %" #op " row_newbcast:" #c " row_mask:0xf bank_mask:0xf\n\t"
+#define GATO_FM32(ac, c, op) "v_fmac_f32_dpp %" #ac ", %2, %" #op " row_newbcast:" #c " row_mask:0xf bank_mask:0xf\n\t"
+#define GATO_FM64_12 GATO_FM64(0, 2) GATO_FM64(1, 3) GATO_FM64(2, 4) GATO_FM64(3, 5) GATO_FM64(4, 6) GATO_FM64(5, 7) \
+    GATO_FM64(6, 8) GATO_FM64(7, 9) GATO_FM64(8, 10) GATO_FM64(9, 11) GATO_FM64(10, 12) GATO_FM64(11, 13)
+#define GATO_FM32_12 GATO_FM32(0, 0, 3) GATO_FM32(1, 1, 4) GATO_FM32(0, 2, 5) GATO_FM32(1, 3, 6) GATO_FM32(0, 4, 7) GATO_FM32(1, 5, 8) \
+    GATO_FM32(0, 6, 9) GATO_FM32(1, 7, 10) GATO_FM32(0, 8, 11) GATO_FM32(1, 9, 12) GATO_FM32(0, 10, 13) GATO_FM32(1, 11, 14)
+#define GATO_M12(m) "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11])
+// acc += sum_{c < N} m[c] * x(lane c of the lane's DPP row), c ascending
+template <int N>
+__device__ __forceinline__ void dpp_block(double &acc, double x, const double *m)
+{
+    static_assert(N == 12 || N == 14 || N == 16, "chain lengths built");
+    if constexpr (N == 12) asm volatile("s_nop 4\n\t" GATO_FM64_12 : "+v"(acc) : "v"(x), GATO_M12(m));
+    else if constexpr (N == 14)
+        asm volatile("s_nop 4\n\t" GATO_FM64_12 GATO_FM64(12, 14) GATO_FM64(13, 15) : "+v"(acc) : "v"(x), GATO_M12(m), "v"(m[12]), "v"(m[13]));
+    else
+        asm volatile("s_nop 4\n\t" GATO_FM64_12 GATO_FM64(12, 14) GATO_FM64(13, 15) GATO_FM64(14, 16) GATO_FM64(15, 17)
+                     : "+v"(acc) : "v"(x), GATO_M12(m), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]));
+}
+// fp32: even columns into a0, odd columns into a1 (the order of the packed-FMA form)
+template <int N>
+__device__ __forceinline__ void dpp_block(float &a0, float &a1, float x, const float *m)
+{
+    static_assert(N == 12 || N == 14 || N == 16, "chain lengths built");
+    if constexpr (N == 12) asm volatile("s_nop 4\n\t" GATO_FM32_12 : "+v"(a0), "+v"(a1) : "v"(x), GATO_M12(m));
+    else if constexpr (N == 14)
+        asm volatile("s_nop 4\n\t" GATO_FM32_12 GATO_FM32(0, 12, 15) GATO_FM32(1, 13, 16) : "+v"(a0), "+v"(a1) : "v"(x), GATO_M12(m), "v"(m[12]), "v"(m[13]));
+    else
+        asm volatile("s_nop 4\n\t" GATO_FM32_12 GATO_FM32(0, 12, 15) GATO_FM32(1, 13, 16) GATO_FM32(0, 14, 17) GATO_FM32(1, 15, 18)
+                     : "+v"(a0), "+v"(a1) : "v"(x), GATO_M12(m), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]));
+}
+// y_row = [L M R]_row . window, window block b given as x[b] (S <= 16: the entry of the lane's row index in knot j-1+b) or as
+// x[2b], x[2b+1] (S = 32: entries (row & 15) and 16 + (row & 15) of that knot).  Call in uniform control flow (all lanes live).
+template <typename T, int S>
+__device__ __forceinline__ T row_times_dpp(const T (&m)[3 * S], const T (&x)[S <= 16 ? 3 : 6])
+{
+    static_assert(DppRows<S>::ok, "no DPP chain for this STATE_SIZE");
+    if constexpr (sizeof(T) == 8) {
+        T acc = (T)0;
+        if constexpr (S <= 16) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) dpp_block<S>(acc, x[b], &m[b * S]);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 6; ++h) dpp_block<16>(acc, x[h], &m[h * 16]);
+        }
+        return acc;
+    } else {
+        T a0 = (T)0, a1 = (T)0;
+        if constexpr (S <= 16) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) dpp_block<S>(a0, a1, x[b], &m[b * S]);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 6; ++h) dpp_block<16>(a0, a1, x[h], &m[h * 16]);
+        }
+        return a0 + a1;
+    }
+}
+
 }  // namespace
 }  // namespace gato

@@ -130,9 +130,16 @@ __device__ __forceinline__ T row_from_memory(const T *__restrict__ src, const T 
 // WPM = poll loads per lane of that form (0 = the gathered form): 4 serves W << ceil(log2(waves)) <= 256 granules (up to 32
 // workgroups of 8 waves).  Measured and rejected: 16 loads per lane for up to 128 workgroups (14/7/4096 f32, W = 114: 4.77 us
 // per iteration against 3.87 gathered - fifteen load instructions per sweep cost more than the gather they replace).
-template <typename T, int S, int MAXT, int NL = 0, int DIAG = 0, int XR = 0, bool NR = false, bool MR = false, int WPM = 0>
+// DR: DPP-row layout (gato_pcg_device.h: row_times_dpp) - a knot owns whole 16-lane DPP rows and the products read their operand
+// window from the neighbouring lanes' REGISTERS (v_fmac_*_dpp row_newbcast) instead of 16-byte LDS reads: the LDS-window
+// products are bound by the LDS return path (fp64 14/7: 1.13 us of a 3.56 us iteration at 15 workgroups, 21 16-byte reads per
+// lane and product), this form reads two scalars per lane and product.  Same summation order per row: identical bits.
+// Plain and cluster launches (NL = 0, XR = 0); lanes S..15 of a row idle (S = 14: 32 knots per 512 threads instead of 36).
+template <typename T, int S, int MAXT, int NL = 0, int DIAG = 0, int XR = 0, bool NR = false, bool MR = false, int WPM = 0, bool DR = false>
 __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
 {
+    static_assert(!DR || (NL == 0 && XR == 0 && !NR && DIAG != 1 && DppRows<S>::ok), "DPP-row layout: plain and cluster variants");
+    constexpr int LPK = DR ? DppRows<S>::lanes : S;                            // lanes per knot
     constexpr bool WP = WPM > 0;            // per-wave published partials
     constexpr bool RG = WPM != 0;           // ghost blocks in the polling lanes' registers (WPM = -1: that alone, gathered partials)
     static_assert(!RG || (NL == 0 && XR == 0 && !NR && DIAG != 1), "wave-published partials / register ghosts: plain and cluster variants");
@@ -187,12 +194,12 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     const int R = MR ? a.nranks : 1;
     const int k0 = k_begin + wg * a.knots_per_wg;
     const int nk = min(a.knots_per_wg, k_end - k0);
-    const int jl = tid / S;                // the lane's slot
-    const int r_ = tid - jl * S;           // row inside the knot
+    const int jl = tid / LPK;              // the lane's slot
+    const int r_ = tid - jl * LPK;         // row inside the knot (DR: rows S..LPK-1 do not exist, those lanes idle)
     const int n_res = NR ? 0 : (XR > 0 ? min(nk, (int)blockDim.x / S) : nk);    // knots with lanes of their own
     const int n_ext = nk - n_res;                                    // knots handled as extra rows (XR > 0 only)
     const int j = (XR > 0 && !NR && n_ext > 0 && jl == n_res - 1) ? nk - 1 : jl;   // local knot: the last slot holds the LAST knot
-    const bool active = jl < n_res;
+    const bool active = jl < n_res && (!DR || r_ < S);
     const int xk = NR ? 0 : n_res - 1;                               // first local knot of the extra rows
     // extra rows of this lane: rows q = tid + e * blockDim.x (e < ne) of the knots [xk, xk + n_ext)
     const int n_ext_rows = n_ext * S;
@@ -718,8 +725,28 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         aborted = s_abort != 0;
     }
     // ---- r~ = Pinv r ; p = r~ ; eta = r . r~   (gato_pcg.cuh:316-335) ------------------------
-    auto pinv_times = [&](const T *xw) -> T {
+    // DR: the operand window of the lane's knot comes from registers - its own block sits in the lanes of its DPP row(s) (`own` =
+    // this lane's entry), the neighbouring knots' entries of the lane's row index are read from the LDS window (two scalars;
+    // written before the last barrier).  Lanes without a row clamp their index: in bounds, finite, times a zero matrix row.
+    auto dpp_times = [&](const auto &mat, int w, T own) -> T {
+        if constexpr (DR) {
+            const T *xw = &xs[w][j * SP];
+            T y;
+            if constexpr (S <= 16) {
+                const int rc = r_ < S ? r_ : S - 1;
+                const T x3[3] = {xw[rc], own, xw[2 * SP + rc]};
+                y = row_times_dpp<T, S>(mat, x3);
+            } else {
+                const int c = r_ & 15;
+                const T x6[6] = {xw[c], xw[16 + c], xw[SP + c], xw[SP + 16 + c], xw[2 * SP + c], xw[2 * SP + 16 + c]};
+                y = row_times_dpp<T, S>(mat, x6);
+            }
+            return active ? y : (T)0;
+        } else return (T)0;
+    };
+    auto pinv_times = [&](const T *xw, T own) -> T {
         if constexpr (NR) return (T)0;
+        else if constexpr (DR) return dpp_times(pm, 1, own);
         else if constexpr (NL > 0) return row_times_window_lds<T, S, SP, NL, MAXT>(pm, ptail, tid, xw);
         else return row_times_window<T, S, SP>(pm, xw);
     };
@@ -745,7 +772,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             if (has_right) xs[0][(nk + 1) * SP + (tid - S)] = dL0[(size_t)(k0 + nk) * S + (tid - S)];
         }
         __syncthreads();
-        if constexpr (!NR) r -= row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
+        if constexpr (DR) r -= dpp_times(sm, 0, lam);
+        else if constexpr (!NR) r -= row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
         if constexpr (XR > 0) (void)extra_rows(dS, 0);                       // product array <- S lambda0 on the extra rows
         __syncthreads();
         if (active) xs[1][(j + 1) * SP + r_] = r;
@@ -775,7 +803,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         else if (tid < 2 * S) xs[0][(nk + 1) * SP + (tid - S)] = (T)0;
         __syncthreads();
     }
-    rt = pinv_times(&xs[1][j * SP]);
+    rt = pinv_times(&xs[1][j * SP], r);
     {
         T prod0 = r * rt;
         if constexpr (XR > 0) prod0 += extra_rows(dP, 1);
@@ -807,6 +835,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             // upsilon = S p ; v = p . upsilon                                     (:349-357)
             GATO_STAMP(5)
             if constexpr (NR) ups = (T)0;
+            else if constexpr (DR) ups = (abl & 1) ? p * sm[0] : dpp_times(sm, 0, p);
             else ups = (abl & 1) ? p * sm[0] : row_times_window<T, S, SP>(sm, &xs[0][j * SP]);
             GATO_STAMP(0)
             T v;
@@ -842,7 +871,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             if (!(abl & 8)) __syncthreads();                                    // B3
             GATO_STAMP(2)
             // r~ = Pinv r ; eta' = r . r~                                        (:380-394)
-            rt = (abl & 2) ? r * pm[0] : pinv_times(&xs[1][j * SP]);
+            rt = (abl & 2) ? r * pm[0] : pinv_times(&xs[1][j * SP], r);
             GATO_STAMP(3)
             {
                 T prod = r * rt;
@@ -1354,6 +1383,69 @@ template <typename T, int S> struct NoresRows {
 template <typename T, int S> struct SingleCu { static constexpr int threads = 0, nl = 0; };
 template <> struct SingleCu<double, 14> { static constexpr int threads = 704, nl = 24; };   // IIWA 14/7/50 fp64
 
+// The plain and the cluster launches (every row register resident): geometry check and the hand-off form.  DR: the DPP-row
+// layout (its instantiations are compiled in gato_pcg_resident_dpp.hip, which includes this file).
+template <typename T, int S, bool DR>
+int launch_plain(const PcgLaunch &a, bool mr, int Kl, hipStream_t st)
+{
+    constexpr int LPK = DR ? DppRows<S>::lanes : S;
+    constexpr int MAXT0 = MaxThreads<T, S>::v;
+    constexpr int SINGLE_T = SingleCu<T, S>::threads;
+    const bool single_lds = !DR && !mr && SINGLE_T > MAXT0 && a.groups == 1 && a.threads > MAXT0 && a.threads <= SINGLE_T;
+    const int MAXT = single_lds ? SINGLE_T : MAXT0;
+    if (a.batch > 1 && a.groups != 1) {
+        set_error("pcg_resident: a batch needs one workgroup per system");
+        return GATO_EINVAL;
+    }
+    if ((DR && a.stamps) || a.threads > MAXT || a.threads % 64 != 0 || a.threads < 2 * S || a.knots_per_wg * LPK > a.threads ||
+        a.groups < 1 || a.groups > 256 || (long long)a.groups * a.knots_per_wg < Kl ||
+        (long long)(a.groups - 1) * a.knots_per_wg >= Kl) {
+        set_error("pcg_resident: bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d max=%d)", a.K,
+                  a.groups, a.knots_per_wg, a.threads, MAXT);
+        return GATO_EINVAL;
+    }
+    // no re-initialisation of the hand-off area: granules carry epochs from the solver's ever-growing counter and
+    // the status word is matched against this launch's id
+    if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
+    const int nblocks = a.batch > 1 ? a.batch
+                      : (a.xcd_pack > 0 ? 8 * ((a.groups + a.xcd_pack - 1) / a.xcd_pack) : a.groups);
+    if constexpr (SINGLE_T > 0 && !DR) {
+        if (single_lds) {
+            constexpr int NL = SingleCu<T, S>::nl;
+            if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, 1>), dim3(nblocks), dim3(a.threads), 0, st, a);
+            else if (a.diag == 2) hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, 2>), dim3(nblocks), dim3(a.threads), 0, st, a);
+            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, false>), dim3(nblocks), dim3(a.threads), 0, st, a);
+            GATO_HIP_CHECK(hipGetLastError());
+            if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
+            return GATO_OK;
+        }
+    }
+    // Hand-off form of the plain and the cluster launches (option wave_pub, default 1): ghost blocks in registers always;
+    // per-wave published partials where a sweep - W << ceil(log2(waves)) granules - is at most 4 loads per lane (up to 32
+    // workgroups of 8 waves).  wave_pub = 0: the gathered form with the ghost blocks staged in LDS (also what the cycle-stamp
+    // build, DIAG = 1, runs).
+    const int nw_ = a.threads / 64, wsh_ = nw_ <= 1 ? 0 : 32 - __builtin_clz((unsigned)(nw_ - 1));
+    const bool rg = a.batch <= 1 && a.wave_pub != 0 && !a.stamps && (a.groups > 1 || mr);
+    const bool wp = rg && a.groups > 1 && nw_ * (int)(sizeof(T) / 4) <= 16 && (a.groups << wsh_) <= 256 && a.wave_pub != 3;
+    const dim3 grid(nblocks), block(a.threads);
+    if (mr) {
+        if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, true, 4, DR>), grid, block, 0, st, a);
+        else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, true, -1, DR>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, true, 0, DR>), grid, block, 0, st, a);
+    } else if (a.stamps) {
+        if constexpr (!DR) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 1>), grid, block, 0, st, a);
+    } else if (a.diag == 2) {
+        if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2, 0, false, false, 4, DR>), grid, block, 0, st, a);
+        else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2, 0, false, false, -1, DR>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2, 0, false, false, 0, DR>), grid, block, 0, st, a);
+    } else if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, false, 4, DR>), grid, block, 0, st, a);
+    else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, false, -1, DR>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, false, 0, DR>), grid, block, 0, st, a);
+    GATO_HIP_CHECK(hipGetLastError());
+    if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
+    return GATO_OK;
+}
+
 template <typename T, int S>
 int pcg_resident_plan(PcgPlan *plan)
 {
@@ -1367,6 +1459,7 @@ int pcg_resident_plan(PcgPlan *plan)
     plan->semi_rows = SemiRows<T, S>::v;
     plan->nores_threads = NoresThreads<T, S>::v;
     plan->nores_rows = NoresRows<T, S>::v;
+    plan->dpp_lanes = DppRows<S>::ok ? DppRows<S>::lanes : 0;
     return GATO_OK;
 }
 
@@ -1383,6 +1476,13 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
                (a.rank == a.nranks - 1) != (a.k_end == a.K))) {
         set_error("pcg_resident(cluster): bad shard rank=%d/%d knots [%d,%d) of %d", a.rank, a.nranks, a.k_begin, a.k_end, a.K);
         return GATO_EINVAL;
+    }
+    if (a.dpp_rows) {
+        if (a.pair || a.semi) {
+            set_error("pcg_resident: the DPP-row layout serves the plain and the cluster launches only");
+            return GATO_EINVAL;
+        }
+        return launch_pcg_resident_dpp<T, S>(a, st);
     }
     if constexpr (sizeof(T) == 4 && S % 2 == 0 && PairThreads<S>::v > 0) {
         if (a.pair) {
@@ -1454,62 +1554,10 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
             return GATO_OK;
         }
     }
-    constexpr int MAXT0 = MaxThreads<T, S>::v;
-    constexpr int SINGLE_T = SingleCu<T, S>::threads;
-    const bool single_lds = !mr && SINGLE_T > MAXT0 && a.groups == 1 && a.threads > MAXT0 && a.threads <= SINGLE_T;
-    const int MAXT = single_lds ? SINGLE_T : MAXT0;
-    if (a.batch > 1 && a.groups != 1) {
-        set_error("pcg_resident: a batch needs one workgroup per system");
-        return GATO_EINVAL;
-    }
-    if (a.threads > MAXT || a.threads % 64 != 0 || a.threads < 2 * S || a.knots_per_wg * S > a.threads ||
-        a.groups < 1 || a.groups > 256 || (long long)a.groups * a.knots_per_wg < Kl ||
-        (long long)(a.groups - 1) * a.knots_per_wg >= Kl) {
-        set_error("pcg_resident: bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d max=%d)", a.K,
-                  a.groups, a.knots_per_wg, a.threads, MAXT);
-        return GATO_EINVAL;
-    }
-    // no re-initialisation of the hand-off area: granules carry epochs from the solver's ever-growing counter and
-    // the status word is matched against this launch's id
-    if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-    const int nblocks = a.batch > 1 ? a.batch
-                      : (a.xcd_pack > 0 ? 8 * ((a.groups + a.xcd_pack - 1) / a.xcd_pack) : a.groups);
-    if constexpr (SINGLE_T > 0) {
-        if (single_lds) {
-            constexpr int NL = SingleCu<T, S>::nl;
-            if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, 1>), dim3(nblocks), dim3(a.threads), 0, st, a);
-            else if (a.diag == 2) hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, 2>), dim3(nblocks), dim3(a.threads), 0, st, a);
-            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, SINGLE_T, NL, false>), dim3(nblocks), dim3(a.threads), 0, st, a);
-            GATO_HIP_CHECK(hipGetLastError());
-            if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
-            return GATO_OK;
-        }
-    }
-    // Hand-off form of the plain and the cluster launches (option wave_pub, default 1): ghost blocks in registers always;
-    // per-wave published partials where a sweep - W << ceil(log2(waves)) granules - is at most 4 loads per lane (up to 32
-    // workgroups of 8 waves).  wave_pub = 0: the gathered form with the ghost blocks staged in LDS (also what the cycle-stamp
-    // build, DIAG = 1, runs).
-    const int nw_ = a.threads / 64, wsh_ = nw_ <= 1 ? 0 : 32 - __builtin_clz((unsigned)(nw_ - 1));
-    const bool rg = a.batch <= 1 && a.wave_pub != 0 && !a.stamps && (a.groups > 1 || mr);
-    const bool wp = rg && a.groups > 1 && nw_ * (int)(sizeof(T) / 4) <= 16 && (a.groups << wsh_) <= 256 && a.wave_pub != 3;
-    const dim3 grid(nblocks), block(a.threads);
-    if (mr) {
-        if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, true, 4>), grid, block, 0, st, a);
-        else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, true, -1>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, true>), grid, block, 0, st, a);
-    } else if (a.stamps) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 1>), grid, block, 0, st, a);
-    else if (a.diag == 2) {
-        if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2, 0, false, false, 4>), grid, block, 0, st, a);
-        else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2, 0, false, false, -1>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2>), grid, block, 0, st, a);
-    } else if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, false, 4>), grid, block, 0, st, a);
-    else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, false, -1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, false>), grid, block, 0, st, a);
-    GATO_HIP_CHECK(hipGetLastError());
-    if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
-    return GATO_OK;
+    return launch_plain<T, S, false>(a, mr, Kl, st);
 }
 
+#ifndef GATO_RESIDENT_DPP_PART
 #define X(S_, C_)                                                      \
     template int pcg_resident_plan<float, S_>(PcgPlan *);              \
     template int pcg_resident_plan<double, S_>(PcgPlan *);             \
@@ -1517,5 +1565,23 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
     template int launch_pcg_resident<double, S_>(const PcgLaunch &, hipStream_t);
 GATO_SHAPES(X)
 #undef X
+#else
+// gato_pcg_resident_dpp.hip: the DPP-row instantiations of the plain and the cluster launches, a translation unit of their own
+// (compile time).  `a` arrives checked and normalised by launch_pcg_resident.
+template <typename T, int S>
+int launch_pcg_resident_dpp(const PcgLaunch &a, hipStream_t st)
+{
+    if constexpr (DppRows<S>::ok) return launch_plain<T, S, true>(a, a.xslots != nullptr, a.k_end - a.k_begin, st);
+    else {
+        set_error("pcg_resident: no DPP-row layout for STATE_SIZE %d", S);
+        return GATO_EINVAL;
+    }
+}
+#define X(S_, C_)                                                          \
+    template int launch_pcg_resident_dpp<float, S_>(const PcgLaunch &, hipStream_t); \
+    template int launch_pcg_resident_dpp<double, S_>(const PcgLaunch &, hipStream_t);
+GATO_SHAPES(X)
+#undef X
+#endif
 
 }  // namespace gato

@@ -48,6 +48,19 @@ def oracle_blocks(S, C, K, dt, seed=13):
 def test_cluster_ranks_in_one_process(S, C, K, R, dt, flat):
     """flat = 1: the one-level exchange (every workgroup's partial straight into every mirror; taken whenever ranks x
     workgroups <= 256); flat = 0: the two-level exchange (what shards beyond 256 workgroups use), forced."""
+    _cluster_case(S, C, K, R, dt, flat)
+
+
+@pytest.mark.parametrize("S,C,K,R,dt,dpp", [(14, 7, 300, 2, np.float32, 1), (14, 7, 4096, 4, np.float32, 1), (14, 7, 4096, 2, np.float64, 0),
+                                            (32, 16, 100, 3, np.float32, 0), (12, 6, 200, 3, np.float64, 0), (12, 6, 200, 3, np.float32, 1)])
+@pytest.mark.parametrize("flat", [1, 0])
+def test_cluster_ranks_in_either_row_layout(S, C, K, R, dt, dpp, flat):
+    """The cluster launches exist in both row layouts (LDS operand windows / DPP rows, solver option dpp_rows): here the one the
+    default does NOT take for the shape, forced."""
+    _cluster_case(S, C, K, R, dt, flat, dpp)
+
+
+def _cluster_case(S, C, K, R, dt, flat, dpp=None):
     from gato_python_amd.solver import Solver
     Sb, Pb, gam = oracle_blocks(S, C, K, dt)
     f64 = dt == np.float64
@@ -56,10 +69,14 @@ def test_cluster_ranks_in_one_process(S, C, K, R, dt, flat):
     sols = [Solver(S, C, K, dt) for _ in range(R)]
     for x in sols:
         x.set_option("cluster_flat", flat)
+        if dpp is not None:
+            x.set_option("dpp_rows", dpp)
     dS, dP, dg = sols[0].to_device(Sb), sols[0].to_device(Pb), sols[0].to_device(gam)
     lam, its = run_cluster_lockstep(sols, dS, dP, dg, tol, mi)
     for x in sols:
         x.check_status()
+        want = dpp if dpp is not None else (1 if (f64 or S > 16) and S in (12, 14, 16, 32) else 0)
+        assert x.get_option("last_dpp") == want, (x.get_option("last_dpp"), want)
     fits_flat = sum(x.get_option("last_groups") for x in sols) <= 256
     assert run_cluster_lockstep.last_flat == (1 if flat and fits_flat else 0)
     assert len(set(its)) == 1 and abs(its[0] - it_o) <= (0 if f64 else 2), (its, it_o)

@@ -242,6 +242,20 @@ def test_golden_fp64_whole_solve(golden_dir, name, S, C, K, seed, dq, tol, mi):
     (6, 3, 900, np.float64, {}),
     (14, 7, 777, np.float64, dict(pcg_threads=128)),              # ragged last workgroup, 87 groups across the XCDs
     (2, 1, 3000, np.float32, dict(pcg_threads=128)),
+    # row layout of the plain launches (option dpp_rows): the one the default does not take for the shape, and one-workgroup launches
+    (14, 7, 512, np.float32, dict(dpp_rows=1)),                   # DPP rows in fp32 at S = 14 (auto keeps the packed-FMA LDS form)
+    (14, 7, 4096, np.float32, dict(dpp_rows=1)),                  # 128 workgroups across the XCDs
+    (14, 7, 512, np.float64, dict(dpp_rows=0)),                   # LDS operand windows in fp64 (auto takes DPP rows)
+    (14, 7, 4096, np.float64, dict(dpp_rows=0)),
+    (32, 16, 1024, np.float32, dict(dpp_rows=0)),
+    (32, 16, 256, np.float64, dict(dpp_rows=0)),
+    (12, 6, 700, np.float32, dict(dpp_rows=1)),
+    (12, 6, 700, np.float64, {}),
+    (14, 7, 30, np.float64, {}),                                  # one workgroup in the DPP-row layout
+    (14, 7, 30, np.float64, dict(dpp_rows=0)),
+    (14, 7, 50, np.float64, dict(dpp_rows=1)),                    # forced: two DPP-row workgroups instead of the mixed-rows kernel
+    (14, 7, 45, np.float32, dict(dpp_rows=1, pcg_threads=768)),   # forced: one DPP-row workgroup of 12 waves instead of two rows per lane
+    (14, 7, 777, np.float64, dict(pcg_threads=128, dpp_rows=0)),
     (14, 7, 512, np.float32, dict(pcg_mode=_lib.PCG_STREAMING)),
     (14, 7, 777, np.float64, dict(pcg_mode=_lib.PCG_STREAMING)),
     (32, 16, 100, np.float32, dict(pcg_mode=_lib.PCG_STREAMING)),
@@ -288,6 +302,10 @@ def test_pcg_variants_against_oracle(S, C, K, dt, opts):
         assert sol.get_option("last_groups") == 1 and sol.get_option("last_threads") == (512 if not opts else 64 * ((K * S + 63) // 64))
     if "pcg_groups" in opts:
         assert sol.get_option("last_groups") >= opts["pcg_groups"]
+    if "dpp_rows" in opts:
+        assert sol.get_option("last_dpp") == opts["dpp_rows"]
+    elif mode == _lib.PCG_RESIDENT and S in (12, 14, 32) and sol.get_option("last_pair") == 0 and not opts:
+        assert sol.get_option("last_dpp") == (1 if f64 or S > 16 else 0)               # what auto takes: fp64, and S = 32
     sol.close()
 
 
@@ -416,6 +434,8 @@ print('Test passed')
 @pytest.mark.parametrize("S,C,K,dt,opts", [(14, 7, 50, np.float64, {}), (14, 7, 50, np.float32, {}),
                                            (14, 7, 300, np.float64, {}), (2, 1, 40, np.float64, dict(pcg_threads=64)),
                                            (14, 7, 900, np.float32, {}),
+                                           (14, 7, 300, np.float64, dict(dpp_rows=0)), (14, 7, 900, np.float32, dict(dpp_rows=1)),
+                                           (32, 16, 200, np.float32, {}),
                                            (14, 7, 300, np.float64, dict(pcg_mode=_lib.PCG_STREAMING)),
                                            (32, 16, 40, np.float32, dict(pcg_mode=_lib.PCG_STREAMING)),
                                            (14, 7, 14500, np.float64, {}),                  # semi-resident launch
@@ -506,6 +526,7 @@ def test_random_resident_geometries():
         sol.set_option("no_single_lds", int(rng.integers(0, 2)))
         sol.set_option("pcg_threads", threads if groups == 0 else 0)
         sol.set_option("pcg_groups", groups)
+        sol.set_option("dpp_rows", int(rng.integers(0, 2)))          # either row layout
         try:
             lam, it = sol.pcg(sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam), 1e-9, 300)
         except _lib.GatoError as e:
@@ -515,6 +536,28 @@ def test_random_resident_geometries():
         assert int(host(it)[0]) == it_o, (K, threads, groups, int(host(it)[0]), it_o)
         assert rel(host(lam), lam_o) < 1e-8, (K, threads, groups)   # summation order differs with the split
         sol.close()
+
+
+@pytest.mark.parametrize("S,C,K,dt", [(32, 16, 256, np.float32), (32, 16, 256, np.float64), (32, 16, 1024, np.float32), (32, 16, 9, np.float64)])
+def test_dpp_rows_same_bits_as_the_lds_windows_where_the_geometry_is_the_same(S, C, K, dt):
+    """At S = 32 a knot has 32 lanes in either row layout, so both take the same launch geometry and the same dot-product
+    grouping: the DPP-row products (v_fmac_*_dpp row_newbcast chains) must then give the very bits of the LDS-window products
+    (fp64: columns left to right; fp32: even + odd columns) - lambda, dz and iters."""
+    s = synth.make_system(S, C, K, seed=5)
+    out = []
+    for dpp in (0, 1):
+        sol = make_solver(S, C, K, dt)
+        sol.set_option("dpp_rows", dpp)
+        dev = sol.upload_system(s)
+        lam, dz = sol.new(S * K), sol.new(sol.N)
+        for tol, mi in ((1e-9 if dt == np.float64 else 1e-5, 200), (0.0, 17)):
+            sol.linsys(*dev, tol, mi, s.rho, lam, dz)
+            out.append((dpp, host(lam).copy(), host(dz).copy(), _read_iters(sol), sol.get_option("last_groups"), sol.get_option("last_threads")))
+            assert sol.get_option("last_dpp") == dpp
+        sol.close()
+    for a, b in ((out[0], out[2]), (out[1], out[3])):
+        assert a[4:] == b[4:], (a[4:], b[4:])
+        assert a[3] == b[3] and a[1].tobytes() == b[1].tobytes() and a[2].tobytes() == b[2].tobytes()
 
 
 def test_mixed_rows_kernel_every_size_it_serves():
