@@ -481,7 +481,8 @@ def test_true_warm_start(S, C, K, dt, opts):
 
 
 @pytest.mark.parametrize("S,C,K,B,dt", [(14, 7, 50, 5, np.float64), (14, 7, 50, 7, np.float32), (2, 1, 5, 33, np.float64),
-                                        (14, 7, 120, 3, np.float64), (32, 16, 6, 4, np.float32), (14, 7, 50, 300, np.float32)])
+                                        (14, 7, 120, 3, np.float64), (32, 16, 6, 4, np.float32), (14, 7, 50, 300, np.float32),
+                                        (14, 7, 20, 9, np.float64), (14, 7, 34, 4, np.float64), (32, 16, 16, 5, np.float32)])   # one DPP-row workgroup per system; 34: not in that layout
 def test_batched_solves(S, C, K, B, dt):
     """B independent systems (shared sparsity, own values) in one call - every stage one
     launch for the whole batch, the PCG one workgroup per system.  Each system must equal its own oracle solve."""
