@@ -24,6 +24,7 @@
 //    the reference's four grid.sync() per iteration become two all-gathers and no barrier.
 //    Granules are double-buffered by epoch parity; every spin is bounded.
 #include "gato_pcg_device.h"
+#include <type_traits>
 
 namespace gato {
 namespace {
@@ -681,15 +682,159 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             aborted = s_abort != 0;
         }
     };
+    // ---- LEAN hand-off: the plain single-GPU launches (RG forms).  Same protocol and same arithmetic as allreduce_and_halo,
+    // with everything that does not change between hand-offs computed ONCE: per-lane 32-bit BYTE offsets inside a parity block
+    // of the hand-off area (stores and loads take the uniform block base in SGPRs plus that offset - no 64-bit address
+    // arithmetic per hand-off; the loads of one sweep differ by a uniform stride, so they share ONE offset register), the
+    // predicates of the storing / decoding lanes, and the poll instantiated per number of loads.  FAST (workgroup-scope stores,
+    // one-XCD launches that verified their placement) is a compile-time argument: the iteration loop exists twice instead of
+    // branching at every store.  The stamps of a diagnostic build said why: of a hand-off's ~2 300 cycles at 15 workgroups
+    // the poll itself was 970, the rest address arithmetic, scalar branches and two wave sums in the polling wave.
+    constexpr bool LEAN = RG && !MR;
+    // KEEP: the polling lanes' load offsets stay in registers for the whole solve; kernels whose matrix rows leave few registers
+    // (fp64 at S = 14, fp32 at S = 32, the 768-thread bound) re-derive them from the lane id at every hand-off instead (a
+    // dozen vector instructions in the polling wave; spilling them costs a memory round trip on the critical path)
+    constexpr int REGCAP = MAXT <= 256 ? 512 : MAXT <= 512 ? 256 : MAXT <= 768 ? 168 : 128;
+    constexpr bool KEEP = REGCAP - 6 * S * (int)(sizeof(T) / 4) >= 120;
+    const int l_wsh = WP ? (nwaves <= 1 ? 0 : 32 - __builtin_clz((unsigned)(nwaves - 1))) : 0;
+    const unsigned l_slotB = (unsigned)slotG * 8u;
+    const unsigned l_st_part = (unsigned)wg * l_slotB + (WP ? (unsigned)__builtin_amdgcn_readfirstlane(wave) * (unsigned)GPV * 8u : 0u);   // uniform
+    const unsigned l_st_halo = (unsigned)wg * l_slotB + (16u + (unsigned)r_ * (unsigned)GPV) * 8u;     // first block; the last block S values further
+    const bool l_hl = LEAN && active && j == 0, l_hr = LEAN && active && j == nk - 1;
+    // poll entry e = lane + 64 m: gathered form = workgroup e; WP = wave (e & mask) of workgroup (e >> wsh).  64 entries are a
+    // whole number of workgroups, so load m reads at the lane's offset of load 0 plus m uniform strides.  Entries beyond the
+    // launch read this workgroup's own granule instead (the other parity's block follows this one: its lines are being written)
+    // and are masked out of the epoch test and of the sum.
+    struct LeanLd { int wi0, wv0; unsigned part, halo; bool want_l, want_r; };
+    auto l_derive = [&](int ln) {
+        LeanLd d;
+        d.wi0 = ln >> l_wsh; d.wv0 = ln & ((1 << l_wsh) - 1);
+        d.part = (unsigned)d.wi0 * l_slotB + (unsigned)d.wv0 * (unsigned)GPV * 8u;
+        d.want_l = loc_left && ln < S; d.want_r = loc_right && ln >= 32 && ln < 32 + S;
+        d.halo = d.want_l ? (unsigned)(wg - 1) * l_slotB + (16u + (unsigned)(S + ln) * (unsigned)GPV) * 8u
+               : d.want_r ? (unsigned)(wg + 1) * l_slotB + (16u + (unsigned)(ln - 32) * (unsigned)GPV) * 8u
+                          : (unsigned)wg * l_slotB;                        // wave 0's own partial granule: always current
+        return d;
+    };
+    const LeanLd l_kept = l_derive(lane);
+    const unsigned l_ld_step = (unsigned)(64 >> l_wsh) * l_slotB;
+    const int l_pm = ((W << l_wsh) + 63) >> 6;
+    typedef __attribute__((address_space(1))) char gchar;
+    auto l_at = [](gu64 *base, unsigned boff) { return (gu64 *)((gchar *)base + boff); };
+    // one sweep of N loads per lane until every granule watched carries the epoch; false = gave up (time-out / another
+    // workgroup reported one)
+    // (returns the lane's sum of the partials it read - in load order, as allreduce_and_halo - and its halo entry)
+    auto l_poll = [&](auto nc, const LeanLd &d, gu64 *pb, T &acc_out, T &hv_out) -> bool {
+        constexpr int N = decltype(nc)::value;
+        const unsigned l_ld_part = d.part, l_ld_halo = d.halo;
+        unsigned long long raw[N][GPV], hraw[GPV];
+        bool valid[N];
+#pragma unroll
+        for (int m = 0; m < N; ++m) valid[m] = d.wi0 + m * (64 >> l_wsh) < W && d.wv0 < nwaves;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spin = 0;; ++spin) {
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                gu64 *pm = l_at(pb, valid[m] ? l_ld_part + (unsigned)m * l_ld_step : (unsigned)wg * l_slotB);
+#pragma unroll
+                for (int g = 0; g < GPV; ++g) raw[m][g] = __hip_atomic_load(pm + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            gu64 *ph = l_at(pb, l_ld_halo);
+#pragma unroll
+            for (int g = 0; g < GPV; ++g) hraw[g] = __hip_atomic_load(ph + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = true;
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                bool okm = true;
+#pragma unroll
+                for (int g = 0; g < GPV; ++g) okm &= (unsigned)(raw[m][g] >> 32) == epoch;
+                ok &= okm | !valid[m];
+            }
+#pragma unroll
+            for (int g = 0; g < GPV; ++g) ok &= (unsigned)(hraw[g] >> 32) == epoch;
+            bool stop = __all(ok), good = stop;
+            if (!stop && (spin & 255u) == 255u) {
+                const bool late = __builtin_amdgcn_s_memrealtime() - t0 > t_limit;
+                const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
+                stop = late || other;
+            }
+            if (stop) {
+                T acc = (T)0;
+#pragma unroll
+                for (int m = 0; m < N; ++m) acc += valid[m] ? Gr::decode(raw[m]) : (T)0;
+                acc_out = acc;
+                hv_out = Gr::decode(hraw);
+                return good;
+            }
+        }
+    };
+    auto handoff_lean = [&](auto fastc, T val, T prod, T &total) {
+        constexpr bool FAST = decltype(fastc)::value;
+        typedef typename std::conditional<FAST, LGr, Gr>::type SG;
+        ++epoch;
+        if constexpr (ABL) {
+            if (abl & 4) { total = (T)1 + prod * (T)1e-30; return; }
+        }
+        if (aborted) { total = (T)0; return; }
+        gu64 *pb = slots + (size_t)(epoch & 1) * W * slotG;                       // this parity's block (uniform)
+        T *wp = wpart[epoch & 1];
+        if constexpr (WP) {
+            const T ws = wave_sum(prod);
+            if (lane == 0) SG::store(l_at(pb, l_st_part), epoch, ws);
+        } else partials_store(wp, wave, lane, prod);
+        if (l_hl) SG::store(l_at(pb, l_st_halo), epoch, val);
+        if (l_hr) SG::store(l_at(pb, l_st_halo + (unsigned)(S * GPV * 8)), epoch, val);
+        if constexpr (!WP) __syncthreads();                                        // B1
+        if (wave == 0) {
+            if constexpr (!WP) {
+                const T mine_tot = partials_total<T, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
+                if (lane == 0) SG::store(l_at(pb, l_st_part), epoch, mine_tot);
+                if (W > 64) __builtin_amdgcn_s_sleep(12);                          // cross-XCD: see allreduce_and_halo
+                else if (W > 32) __builtin_amdgcn_s_sleep(10);
+            }
+            LeanLd d = l_kept;
+            if constexpr (!KEEP) {                   // re-derived behind an empty asm the compiler cannot hoist out of the loop
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                d = l_derive(ln);
+            }
+            bool done;
+            T acc, hv;
+            if (l_pm == 1) done = l_poll(std::integral_constant<int, 1>{}, d, pb, acc, hv);
+            else if (l_pm == 2) done = l_poll(std::integral_constant<int, 2>{}, d, pb, acc, hv);
+            else if (l_pm == 3) done = l_poll(std::integral_constant<int, 3>{}, d, pb, acc, hv);
+            else done = l_poll(std::integral_constant<int, 4>{}, d, pb, acc, hv);
+            const T tot = wave_sum(acc);
+            hv_reg = (d.want_l || d.want_r) ? hv : (T)0;
+            if (lane == 0) {
+                if (!done) {
+                    __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_abort = 1;
+                }
+                bc[epoch & 1] = tot;
+            }
+        }
+        __syncthreads();                                                           // B2
+        total = bc[epoch & 1];
+        aborted = s_abort != 0;
+    };
     const bool flat = MR && a.flat != 0;
-    auto exchange = [&](T val, T prod, T &total) {
-        if (flat) allreduce_flat(val, prod, total);
+    auto exchange = [&](auto fastc, T val, T prod, T &total) {
+        if constexpr (LEAN) handoff_lean(fastc, val, prod, total);
+        else if (flat) allreduce_flat(val, prod, total);
         else allreduce_and_halo(val, prod, total);
+    };
+    // outside the iteration loop: the store scope as a run-time choice
+    auto exchange_rt = [&](T val, T prod, T &total) {
+        if constexpr (LEAN && WP) {
+            if (fast_st) exchange(std::true_type{}, val, prod, total);
+            else exchange(std::false_type{}, val, prod, total);
+        } else exchange(std::false_type{}, val, prod, total);
     };
 
     // ---- one-XCD launches: are we really on one XCD?  One extra all-to-all round (agent scope) with the XCC id as payload;
     // every workgroup reads the same W ids, so all take the same decision.  ~0.7 us once per launch.
-    if (!MR && X > 0 && W > 1 && W <= 64 && !(abl & 4)) {
+    if ((WP || !LEAN) && !MR && X > 0 && W > 1 && W <= 64 && !(abl & 4)) {      // (the lean gathered form keeps agent scope: no round)
         __shared__ int s_same;
         ++epoch;
         if (wave == 0) {
@@ -789,7 +934,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         }
         if (multi) {
             T dummy;
-            exchange(r, (T)0, dummy);
+            exchange_rt(r, (T)0, dummy);
             if constexpr (RG) {
                 g_r = hv_reg;
                 if (g_lane) xs[1][gslot] = g_r;
@@ -807,7 +952,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     {
         T prod0 = r * rt;
         if constexpr (XR > 0) prod0 += extra_rows(dP, 1);
-        exchange(rt, prod0, eta);
+        exchange_rt(rt, prod0, eta);
     }
     const bool rec_on = a.eta_hist != nullptr;                 // wave-uniform: one scalar branch when recording is off
     const bool rec = wg == 0 && tid == 0 && sys == 0;
@@ -831,6 +976,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         }
         __syncthreads();
 
+        auto iterate = [&](auto fastc) {
         for (int it = 0; it < a.max_iters; ++it) {                              // gato_pcg.cuh:348
             // upsilon = S p ; v = p . upsilon                                     (:349-357)
             GATO_STAMP(5)
@@ -842,7 +988,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             {
                 T prod = p * ups;
                 if constexpr (XR > 0) prod += extra_rows(dS, 0);
-                exchange(ups, prod, v);
+                exchange(fastc, ups, prod, v);
             }
             GATO_STAMP(1)
             if (aborted) break;
@@ -876,7 +1022,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             {
                 T prod = r * rt;
                 if constexpr (XR > 0) prod += extra_rows(dP, 1);
-                exchange(rt, prod, eta_new);
+                exchange(fastc, rt, prod, eta_new);
             }
             GATO_STAMP(4)
             if (aborted) break;
@@ -907,6 +1053,11 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             eta = eta_new;                                                      // :420
             if (!(abl & 8)) __syncthreads();                                    // B6
         }
+        };
+        if constexpr (LEAN && WP) {                 // the loop twice: workgroup-scope stores (verified one-XCD placement) / agent scope
+            if (fast_st) iterate(std::true_type{});
+            else iterate(std::false_type{});
+        } else iterate(std::false_type{});
     }
     if (active) dL[(size_t)k * S + r_] = lam;                                   // :433-435
 #pragma unroll 1
@@ -1428,19 +1579,30 @@ int launch_plain(const PcgLaunch &a, bool mr, int Kl, hipStream_t st)
     const bool rg = a.batch <= 1 && a.wave_pub != 0 && !a.stamps && (a.groups > 1 || mr);
     const bool wp = rg && a.groups > 1 && nw_ * (int)(sizeof(T) / 4) <= 16 && (a.groups << wsh_) <= 256 && a.wave_pub != 3;
     const dim3 grid(nblocks), block(a.threads);
-    if (mr) {
-        if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, true, 4, DR>), grid, block, 0, st, a);
-        else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, true, -1, DR>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, true, 0, DR>), grid, block, 0, st, a);
-    } else if (a.stamps) {
-        if constexpr (!DR) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 1>), grid, block, 0, st, a);
-    } else if (a.diag == 2) {
-        if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2, 0, false, false, 4, DR>), grid, block, 0, st, a);
-        else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2, 0, false, false, -1, DR>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 2, 0, false, false, 0, DR>), grid, block, 0, st, a);
-    } else if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, false, 4, DR>), grid, block, 0, st, a);
-    else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, false, -1, DR>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 0, 0, false, false, 0, DR>), grid, block, 0, st, a);
+    // launch bound of the instantiation: shapes whose bound is above 512 threads (fp32, S <= 16: 768 threads = 168 registers per
+    // lane) also exist with a bound of 512 (256 registers) for the launches that fit it - most multi-workgroup launches are 512
+    // threads, and the hand-off's loop-invariant offsets do not fit 168 registers beside the matrix rows (spills)
+    auto go = [&](auto mtc) {
+        constexpr int MT = decltype(mtc)::value;
+        if (mr) {
+            if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, true, 4, DR>), grid, block, 0, st, a);
+            else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, true, -1, DR>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, true, 0, DR>), grid, block, 0, st, a);
+        } else if (a.stamps) {
+            if constexpr (!DR) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 1>), grid, block, 0, st, a);
+        } else if (a.diag == 2) {
+            if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 2, 0, false, false, 4, DR>), grid, block, 0, st, a);
+            else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 2, 0, false, false, -1, DR>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 2, 0, false, false, 0, DR>), grid, block, 0, st, a);
+        } else if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, false, 4, DR>), grid, block, 0, st, a);
+        else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, false, -1, DR>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, false, 0, DR>), grid, block, 0, st, a);
+    };
+    constexpr bool HAS512 = MAXT0 > 512 && S >= 12;
+    if constexpr (HAS512) {
+        if (a.threads <= 512 && a.batch <= 1) go(std::integral_constant<int, 512>{});
+        else go(std::integral_constant<int, MAXT0>{});
+    } else go(std::integral_constant<int, MAXT0>{});
     GATO_HIP_CHECK(hipGetLastError());
     if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
     return GATO_OK;
