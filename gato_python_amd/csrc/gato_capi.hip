@@ -644,10 +644,11 @@ static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int
              (!s->no_pair && !s->no_single_lds && s->plan.mixed_rows > 0 && K * S <= s->plan.mixed_rows && K * S > maxT && !s->cl.on && K == s->d.K) ||
              (K * S > maxT && K * S <= s->plan.single_max_threads && !s->no_single_lds));
         const bool batch_split = s->d.B > 1 && K * L > maxT && K * S <= maxT;          // a batch needs one workgroup per system
-        // measured (tools/dpp_ab.py, same box): fp64 -7..-21 % per iteration at S = 12 / 14 / 32, fp32 -7..-14 % at S = 32; fp32 at
-        // S <= 16 gains nothing (its packed-FMA products are not LDS bound) and loses lanes to the idle rows (14/7/4096: 128
-        // workgroups instead of 114, +1 %)
-        const bool pays = s->esz == 8 || S > 16;
+        // measured (tools/dpp_ab.py, same box, with the lean hand-off): fp64 14/7/512 2.76 -> 2.56 us per iteration, 14/7/1024
+        // 2.94 -> 2.75, 32/16/1024 6.35 -> 5.10, one workgroup 14/7/20 1.71 -> 1.35 (14/7/4096 and 12/6/300 equal); fp32 keeps
+        // the LDS windows with packed FMAs: 14/7/512 2.17 against 2.21, 32/16/256 2.53 against 2.78 (the DPP-row kernel spills
+        // there), 32/16/1024 3.73 against 3.70, 12/6/300 1.86 against 2.13 (idle lanes cost workgroups)
+        const bool pays = s->esz == 8;
         if ((s->dpp_rows > 0 || (pays && !one_wg_kernel && !batch_split)) && plan_dpp_rows(s, K, L, max_wg, groups, threads, kpw)) {
             s->plan_pair = 0;
             s->plan_dpp = 1;

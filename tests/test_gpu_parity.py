@@ -247,7 +247,7 @@ def test_golden_fp64_whole_solve(golden_dir, name, S, C, K, seed, dq, tol, mi):
     (14, 7, 4096, np.float32, dict(dpp_rows=1)),                  # 128 workgroups across the XCDs
     (14, 7, 512, np.float64, dict(dpp_rows=0)),                   # LDS operand windows in fp64 (auto takes DPP rows)
     (14, 7, 4096, np.float64, dict(dpp_rows=0)),
-    (32, 16, 1024, np.float32, dict(dpp_rows=0)),
+    (32, 16, 1024, np.float32, dict(dpp_rows=1)),
     (32, 16, 256, np.float64, dict(dpp_rows=0)),
     (12, 6, 700, np.float32, dict(dpp_rows=1)),
     (12, 6, 700, np.float64, {}),
@@ -305,7 +305,7 @@ def test_pcg_variants_against_oracle(S, C, K, dt, opts):
     if "dpp_rows" in opts:
         assert sol.get_option("last_dpp") == opts["dpp_rows"]
     elif mode == _lib.PCG_RESIDENT and S in (12, 14, 32) and sol.get_option("last_pair") == 0 and not opts:
-        assert sol.get_option("last_dpp") == (1 if f64 or S > 16 else 0)               # what auto takes: fp64, and S = 32
+        assert sol.get_option("last_dpp") == (1 if f64 else 0)                         # what auto takes: fp64
     sol.close()
 
 
@@ -435,7 +435,7 @@ print('Test passed')
                                            (14, 7, 300, np.float64, {}), (2, 1, 40, np.float64, dict(pcg_threads=64)),
                                            (14, 7, 900, np.float32, {}),
                                            (14, 7, 300, np.float64, dict(dpp_rows=0)), (14, 7, 900, np.float32, dict(dpp_rows=1)),
-                                           (32, 16, 200, np.float32, {}),
+                                           (32, 16, 200, np.float32, dict(dpp_rows=1)),
                                            (14, 7, 300, np.float64, dict(pcg_mode=_lib.PCG_STREAMING)),
                                            (32, 16, 40, np.float32, dict(pcg_mode=_lib.PCG_STREAMING)),
                                            (14, 7, 14500, np.float64, {}),                  # semi-resident launch
@@ -482,7 +482,7 @@ def test_true_warm_start(S, C, K, dt, opts):
 
 @pytest.mark.parametrize("S,C,K,B,dt", [(14, 7, 50, 5, np.float64), (14, 7, 50, 7, np.float32), (2, 1, 5, 33, np.float64),
                                         (14, 7, 120, 3, np.float64), (32, 16, 6, 4, np.float32), (14, 7, 50, 300, np.float32),
-                                        (14, 7, 20, 9, np.float64), (14, 7, 34, 4, np.float64), (32, 16, 16, 5, np.float32)])   # one DPP-row workgroup per system; 34: not in that layout
+                                        (14, 7, 20, 9, np.float64), (14, 7, 34, 4, np.float64), (32, 16, 16, 5, np.float64)])   # one DPP-row workgroup per system; 34: not in that layout
 def test_batched_solves(S, C, K, B, dt):
     """B independent systems (shared sparsity, own values) in one call - every stage one
     launch for the whole batch, the PCG one workgroup per system.  Each system must equal its own oracle solve."""
