@@ -724,6 +724,16 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     // one sweep of N loads per lane until every granule watched carries the epoch; false = gave up (time-out / another
     // workgroup reported one)
     // (returns the lane's sum of the partials it read - in load order, as allreduce_and_halo - and its halo entry)
+    // Sleep before the first sweep (launches across XCDs; gathered form), in units of ~74 cycles (s_sleep 1 + the loop).  A
+    // sweep that comes before the last publisher's store has crossed the fabric is wasted and the next one costs a whole
+    // round trip more; a sweep that comes late wastes the difference.  Swept with this hand-off (tools/sleep_sweep.py on a scratch
+    // build; us per iteration): 14/7/4096 f32 (W = 114) 12: 3.64, 14: 3.56, 16: 3.40, 18: 3.46; 14/7/2048 f32 (57) 12: 3.25,
+    // 14: 3.13, 16: 3.22; 14/7/4096 f64 (128) 12: 4.40, 14: 4.18, 16: 4.24; 32/16/1024 f32 (64) 10: 3.71, 12: 3.60, 14: 3.69;
+    // 32/16/2048 f32 (128) 12: 4.20, 14: 4.01, 16: 4.09 - the optimum grows with the number of workgroups (their skew).  A
+    // controller in the polling wave (failed first sweep -> longer, a run of successes -> shorter) was tried and lost: one
+    // workgroup's probe that fails delays everybody's next hand-off, so 114 independent probes keep the whole launch inflated
+    // (3.58 against 3.40 with the fixed value).
+    const int l_sleep = W > 32 ? 10 + W / 22 : 0;
     auto l_poll = [&](auto nc, const LeanLd &d, gu64 *pb, T &acc_out, T &hv_out) -> bool {
         constexpr int N = decltype(nc)::value;
         const unsigned l_ld_part = d.part, l_ld_halo = d.halo;
@@ -789,8 +799,9 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             if constexpr (!WP) {
                 const T mine_tot = partials_total<T, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
                 if (lane == 0) SG::store(l_at(pb, l_st_part), epoch, mine_tot);
-                if (W > 64) __builtin_amdgcn_s_sleep(12);                          // cross-XCD: see allreduce_and_halo
-                else if (W > 32) __builtin_amdgcn_s_sleep(10);
+            }
+            if constexpr (!WP) {
+                for (int i = 0; i < l_sleep; ++i) __builtin_amdgcn_s_sleep(1);
             }
             LeanLd d = l_kept;
             if constexpr (!KEEP) {                   // re-derived behind an empty asm the compiler cannot hoist out of the loop

@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gato_python_amd import synth
 from gato_python_amd.solver import Solver
-names = ["wave sum + own stores", "(B1 + gather + own total) + offsets", "poll + decode", "wave sum + bc write", "B2 + bc read", "-", "update + window barrier + product", "-"]
-for (S, C, K, dt, dpp) in [(14, 7, 512, np.float32, 0), (14, 7, 512, np.float64, 1), (14, 7, 4096, np.float32, 0), (32, 16, 1024, np.float32, 1)]:
+names = ["wave sum + own stores", "gather + own total + offsets", "poll + decode", "wave sum + bc write", "B2 + bc read", "B1 (gathered form)", "update + window barrier + product", "-"]
+for (S, C, K, dt, dpp) in [(14, 7, 512, np.float32, 0), (14, 7, 512, np.float64, 1), (14, 7, 4096, np.float32, 0), (14, 7, 4096, np.float32, 1), (14, 7, 4096, np.float64, 1), (32, 16, 1024, np.float32, 0)]:
     s = synth.make_system(S, C, K, seed=0)
     sol = Solver(S, C, K, dt); sol.set_option("dpp_rows", dpp); sol.set_option("record_eta", 1)
     dev = sol.upload_system(s); lam, dz = sol.new(S * K), sol.new(sol.N)
