@@ -141,7 +141,15 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
             unsigned long long raw[PM][2 * GPV], hraw[2][GPV];
             const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
             bool fail = false;
-            if (W > 32) __builtin_amdgcn_s_sleep(10);   // see the same line in gato_pcg_resident.hip: -6..-17 % here
+            // sleep before the first sweep of a cross-XCD hand-off (round 1: s_sleep 10, -6..-17 % here): with 512-thread workgroups
+            // the W-dependent rule of gato_pcg_resident.hip (l_sleep; 14/7/4096 f32 2.87 -> 2.72 us); with 256-thread workgroups
+            // (32/16, fp64) that rule overshoots (32/16/1024 f32 3.06 -> 3.25): they keep the old value
+            if (W > 32) {
+                if (blockDim.x >= 512) {
+                    const int sl = 10 + W / 22;
+                    for (int i = 0; i < sl; ++i) __builtin_amdgcn_s_sleep(1);
+                } else __builtin_amdgcn_s_sleep(10);
+            }
             for (unsigned spin = 0;; ++spin) {
 #pragma unroll
                 for (int m = 0; m < PM; ++m)
