@@ -648,7 +648,9 @@ static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int
         // 2.94 -> 2.75, 32/16/1024 6.35 -> 5.10, one workgroup 14/7/20 1.71 -> 1.35 (14/7/4096 and 12/6/300 equal); fp32 keeps
         // the LDS windows with packed FMAs: 14/7/512 2.17 against 2.21, 32/16/256 2.53 against 2.78 (the DPP-row kernel spills
         // there), 32/16/1024 3.73 against 3.70, 12/6/300 1.86 against 2.13 (idle lanes cost workgroups)
-        const bool pays = s->esz == 8;
+        // (cluster launches still run the older hand-off, where the LDS-window kernel at S = 32 is the slower one: one-GPU
+        //  rehearsal of 32/16/1024 f32 over 2 ranks 4.62 us per iteration with DPP rows, 4.9 without)
+        const bool pays = s->esz == 8 || (S > 16 && s->cl.on);
         if ((s->dpp_rows > 0 || (pays && !one_wg_kernel && !batch_split)) && plan_dpp_rows(s, K, L, max_wg, groups, threads, kpw)) {
             s->plan_pair = 0;
             s->plan_dpp = 1;

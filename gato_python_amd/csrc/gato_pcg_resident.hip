@@ -630,6 +630,12 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
                 for (int m = 0; m < Cfg::PM; ++m) pptr[m] = pbase + (size_t)min(ln + 64 * m, WT - 1) * slotG;
                 const int pm_count = (WT + 63) >> 6;
                 unsigned long long raw[Cfg::PM][GPV], hraw[GPV];
+                // sleep before the first sweep as in the single-GPU launches (l_sleep below): the partials of WT workgroups cross
+                // the XCDs' fabric at least; across GPUs the peers' stores take longer still
+                if (WT > 32) {
+                    const int sl = 10 + WT / 22;
+                    for (int i = 0; i < sl; ++i) __builtin_amdgcn_s_sleep(1);
+                }
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 bool fail = false;
                 for (unsigned spin = 0;; ++spin) {
