@@ -235,6 +235,8 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
             if (c < NREG) pm[c < NREG ? c : 0] = pv_;
             else ptail[(c - NREG) / VecOf<T>::W][tid][(c - NREG) % VecOf<T>::W] = pv_;   // own lane only: no barrier
         }
+        // (issuing all 6S loads first and selecting afterwards - what pays in the one-workgroup kernels below - measured no
+        //  better here: 14/7/1024 f32 2.34 -> 2.31 but 14/7/4096 f32 3.44 -> 3.53, 32/16/256 2.53 -> 2.62 us per iteration)
     }
 
     // ---- hand-off area ----------------------------------------------------------------------
@@ -1178,10 +1180,14 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
     {
         const size_t base = (size_t)(active ? j : 0) * 3 * S * S;
 #pragma unroll
-        for (int c = 0; c < 3 * S; ++c) {
+        for (int c = 0; c < 3 * S; ++c) sm[c] = *reinterpret_cast<const f32x2 *>(dS + base + c * S + r0);   // even index: 8-byte aligned
+#pragma unroll
+        for (int c = 0; c < 3 * S; ++c) pm[c] = *reinterpret_cast<const f32x2 *>(dP + base + c * S + r0);
+#pragma unroll
+        for (int c = 0; c < 3 * S; ++c) {        // (the selects after ALL loads: see pcg_single_f64m_kernel; 14/7/50 f32 1.423 -> 1.408 us per iteration)
             const bool ok = active && !(j == 0 && c < S) && !(j == K - 1 && c >= 2 * S);   // gato_utils.cuh:157-174
-            sm[c] = ok ? *reinterpret_cast<const f32x2 *>(dS + base + c * S + r0) : f32x2{0.f, 0.f};     // even index: 8-byte aligned
-            pm[c] = ok ? *reinterpret_cast<const f32x2 *>(dP + base + c * S + r0) : f32x2{0.f, 0.f};
+            sm[c] = ok ? sm[c] : f32x2{0.f, 0.f};
+            pm[c] = ok ? pm[c] : f32x2{0.f, 0.f};
         }
     }
     for (int i = tid; i < 2 * (MAXK + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = 0.f;
