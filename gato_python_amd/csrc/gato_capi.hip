@@ -179,7 +179,8 @@ struct gato_solver {
         int mem_kind;                 // 0 uncached, 1 fine-grained, 2 plain hipMalloc
     } cl;
     struct { const void *Ginv, *Cd, *g; void *dz; } fz;   // set by the whole-solve entries: dz may ride in the PCG launch
-    int dz_fused;                     // the most recent PCG launch also did the dz back-substitution
+    int dz_fused;                     // the most recent PCG launch also did the dz back-substitution (1: in the solving workgroup, 2: in helper blocks)
+    int *dz_flag;                     // device word for the helper blocks of the one-workgroup fp64 launch
     int no_fuse_dz;                   // option
     unsigned long long **cl_tab;      // device copy of cl.peer (the kernel reads the peers' mirror addresses from it)
 };
@@ -398,6 +399,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     s->iters = B > 1 ? (int *)(a + o_its) : (int *)(a + o_status + 8);
     s->final_eta = (double *)(a + o_status + 16);
     s->tune_status = (int *)(a + o_status + 32); s->tune_iters = (int *)(a + o_status + 40); s->tune_eta = (double *)(a + o_status + 48);
+    s->dz_flag = (int *)(a + o_status + 56);
     s->G_dense = a + o_G; s->C_dense = a + o_C; s->Ginv = a + o_Gi;
     s->Sbd = a + o_S; s->Pbd = a + o_P; s->gamma = a + o_gam; s->lambda = a + o_lam; s->dz = a + o_dz;
     s->sw.vecs = a + o_vec;
@@ -891,6 +893,14 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         if (s->fz.dz && (s->no_fuse_dz < 0 || (!s->no_fuse_dz && batch > 1)) && groups == 1 && !cg1 && s->plan_pair != 1 && !a.semi && !s->stamp_pcg) {
             a.dz_Ginv = s->fz.Ginv; a.dz_Cd = s->fz.Cd; a.dz_g = s->fz.g; a.dz = s->fz.dz; a.C = s->d.C;
             s->dz_fused = 1;
+        }
+        // ONE system through the one-workgroup fp64 kernel (pcg_single_f64m_kernel, BASELINE configs[1]): its helper blocks - there
+        // to warm the L2 - stay and do dz as soon as lambda is published: the dz launch and the gap in front of it (6.5 us of a
+        // 215 us step) become ~1 us at the end of the PCG launch.  no_fuse_dz = 1 keeps the launch of its own.
+        else if (s->fz.dz && !s->no_fuse_dz && batch == 1 && groups == 1 && !cg1 && s->plan_pair == 2 && !s->stamp_pcg && !s->tuning) {
+            a.dz_Ginv = s->fz.Ginv; a.dz_Cd = s->fz.Cd; a.dz_g = s->fz.g; a.dz = s->fz.dz; a.C = s->d.C;
+            a.dz_helpers = 1; a.dz_flag = s->dz_flag;
+            s->dz_fused = 2;
         }
         a.ablate = s->ablate;
         a.stamps = s->stamp_pcg == 1 ? (unsigned long long *)s->sw.scalars + 8 : nullptr;

@@ -179,6 +179,8 @@ struct PcgLaunch {
     const void *dz_Ginv, *dz_Cd, *dz_g;
     void *dz;
     int C;
+    int dz_helpers;              // 1: the helper blocks of the one-workgroup fp64 launch do the dz back-substitution once *dz_flag == launch_id
+    int *dz_flag;                // device word: the solving workgroup stores launch_id there when lambda is complete
     // flat variant of the cluster exchange (ranks x workgroups <= 256): every workgroup stores its partial straight into
     // every rank's mirror and its boundary blocks into its own and (at the rank's edges) the neighbour's - ONE level, no
     // wait for the rank's own gather first.  The flat area follows the two-level area in every mirror.

@@ -78,6 +78,14 @@ template <typename T> using GranuleSys = GranuleT<T, __HIP_MEMORY_SCOPE_SYSTEM>;
 
 constexpr int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
+// LDS hand-over inside ONE wave (a lane reads what another lane of the same wave wrote): the wave's LDS operations execute in
+// order, so all that is needed is that the compiler keeps them in order too.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // alpha = eta / v and beta = eta' / eta sit on the critical path of every iteration, in every lane; the IEEE division
 // sequence (v_div_scale, v_rcp, 7 FMAs, v_div_fmas, v_div_fixup) costs 0.09 us each in fp64 on one CU.  Here: quotient
 // of the MANTISSAS (both in [0.5, 1): no range problems whatever the operands) by hardware reciprocal + one Newton step

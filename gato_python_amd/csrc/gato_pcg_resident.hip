@@ -1315,6 +1315,81 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
             acc ^= s4[u] ^ p4[u];
         }
         asm volatile("" ::"v"(acc));
+        // ... and then stay for the dz back-substitution (compute_dz, gato_schur.cuh:758-867): wave w of helper h takes knot
+        // h * WT + w, brings Q_k^-1, R_k^-1, A_k, B_k and g_k into LDS while the solve runs, waits (sleeping) until the solving
+        // workgroup has stored launch_id in *dz_flag - lambda is complete and released - and finishes in about a microsecond.
+        // That replaces a launch of its own (5.3 us + the gap in front of it) at the end of every step.  Formulas and
+        // accumulation order of dz_kernel (gato_assembly.hip), row by row: the same bits.  The solving workgroup never waits for
+        // a helper, so helpers that are scheduled late (or after it has finished) just find the flag set.
+        if (a.dz_helpers && a.dz != nullptr) {
+            const int kq = (int)h * WT + wave;
+            if (kq >= K) return;
+            const int Cn = a.C, n = S + Cn, SS = S * S;
+            const size_t gs = (size_t)(SS + Cn * Cn), cs = (size_t)(SS + S * Cn);
+            const T *__restrict__ Qg = static_cast<const T *>(a.dz_Ginv) + (size_t)kq * gs;
+            const T *__restrict__ Ag = static_cast<const T *>(a.dz_Cd) + (size_t)kq * cs;
+            const T *__restrict__ gg = static_cast<const T *>(a.dz_g) + (size_t)kq * n;
+            const T *__restrict__ lg = static_cast<const T *>(a.lambda) + (size_t)kq * S;
+            T *__restrict__ dzo = static_cast<T *>(a.dz) + (size_t)kq * n;
+            const bool last = kq == K - 1;
+            T *scr = reinterpret_cast<T *>(&ptail[0][0]) + (size_t)wave * (4 * SS + 6 * S);       // this wave's own part of the LDS
+            T *sQi = scr, *sA = sQi + SS, *sRi = sA + SS, *sB = sRi + SS, *sl = sB + SS, *st = sl + 2 * S, *sg = st + 2 * S;
+            static_assert((size_t)WT * (4 * S * S + 6 * S) * sizeof(T) <= sizeof(ptail), "dz scratch of the helper waves");
+            for (int i = lane; i < SS; i += 64) sQi[i] = Qg[i];
+            for (int i = lane; i < (last ? S : n); i += 64) sg[i] = gg[i];
+            if (!last) {
+                for (int i = lane; i < Cn * Cn; i += 64) sRi[i] = Qg[SS + i];
+                for (int i = lane; i < SS; i += 64) sA[i] = Ag[i];
+                for (int i = lane; i < S * Cn; i += 64) sB[i] = Ag[SS + i];
+            }
+            gi32 *flag = (gi32 *)a.dz_flag;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool late = false;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.launch_id) {
+                __builtin_amdgcn_s_sleep(4);                      // ~0.1 us between looks: 50 waves, one load each
+                if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { late = true; break; }
+            }
+            if (late) {         // cannot happen unless the solving workgroup died: report it like a hand-off time-out
+                if (lane == 0) __hip_atomic_store((gi32 *)a.status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (int i = lane; i < (last ? S : 2 * S); i += 64) sl[i] = __hip_atomic_load(lg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wave_lds_fence();
+            if (!last) {
+                for (int i = lane; i < S; i += 64) {                                  // A_k^T lambda_{k+1}   :833-838
+                    T res = (T)0;
+#pragma unroll
+                    for (int t = 0; t < S; ++t) res = gato::fmaT(sA[i * S + t], sl[S + t], res);
+                    st[i] = res;
+                }
+                for (int i = lane; i < Cn; i += 64) {                                 // B_k^T lambda_{k+1}   :784-789
+                    T res = (T)0;
+#pragma unroll
+                    for (int t = 0; t < S; ++t) res = gato::fmaT(sB[i * S + t], sl[S + t], res);
+                    st[S + i] = res;
+                }
+                wave_lds_fence();
+                for (int i = lane; i < S; i += 64) st[i] = sg[i] - (sl[i] + st[i]);                    // :841-852
+                for (int i = lane; i < Cn; i += 64) st[S + i] = sg[S + i] - st[S + i];                 // :792-796
+            } else {
+                for (int i = lane; i < S; i += 64) st[i] = sg[i] - sl[i];             // last state row (D2)
+            }
+            wave_lds_fence();
+            for (int r = lane; r < S; r += 64) {                                      // Q_k^-1 (...)         :856-865
+                T res = (T)0;
+#pragma unroll
+                for (int cc = 0; cc < S; ++cc) res = gato::fmaT(sQi[r + cc * S], st[cc], res);
+                dzo[r] = res;
+            }
+            if (!last) {
+                for (int r = lane; r < Cn; r += 64) {                                 // R_k^-1 (...)         :799-808
+                    T res = (T)0;
+                    for (int cc = 0; cc < Cn; ++cc) res = gato::fmaT(sRi[r + cc * Cn], st[S + cc], res);
+                    dzo[S + r] = res;
+                }
+            }
+        }
         return;
     }
     const size_t sys = a.batch > 1 ? blockIdx.x : 0;
@@ -1477,9 +1552,14 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         dL[(size_t)j * S + r0] = lam[0];
         if (two) dL[(size_t)j * S + r0 + 1] = lam[1];
     }
+    if (a.dz_helpers && a.dz != nullptr && a.batch <= 1) {       // lambda is complete: release it and tell the helper blocks
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store((gi32 *)a.dz_flag, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ---- dz back-substitution in the same launch (batches: one workgroup per system).  Formulas and accumulation order of
     // dz_kernel (gato_assembly.hip; gato_schur.cuh:758-867, D2 fixed), row by row: bit-identical results.
-    if (a.dz != nullptr) {
+    if (a.dz != nullptr && !a.dz_helpers) {
         const int Cn = a.C, n = S + Cn, k = j, nrow = two ? 2 : 1;
         const size_t gs = (size_t)(S * S + Cn * Cn), cs = (size_t)(S * S + S * Cn), Nn = (size_t)n * K - Cn;
         const T *__restrict__ Gi = static_cast<const T *>(a.dz_Ginv) + sys * (gs * K - (size_t)Cn * Cn);
