@@ -42,7 +42,7 @@ if trace:
             # one-XCD launches (8x oversubscribed grid of the plain resident / single-reduction kernels): creating a solver
             # (gato_solver_create -> gato_solver_tune) runs 16 short trial launches (16 iterations each) - listed apart
             trials = []
-            packed = re.match(r"pcg_resident_kernel<\w+, \d+, \d+, 0, 0, 0, false, false(, -?\d+)?>|pcg_cg1_kernel<", k[0]) and k[1] >= 16 * k[2]
+            packed = re.match(r"pcg_resident_kernel<\w+, \d+, \d+, 0, 0, 0, false, false(, -?\d+)?(, (true|false))?>|pcg_cg1_kernel<", k[0]) and k[1] >= 16 * k[2]
             if packed and len(v) > 16 and max(v) > 3 * min(v):
                 cut = max(v) / 3
                 short_ = [x for x in v if x < cut]
