@@ -313,7 +313,9 @@ def committed_traffic(name, res=None):
         want = res["pcg_groups"] * res["pcg_threads"]
         fam = "double" if res["dtype"] == "f64" else "float"
         k = e.get("kernel", "")
-        if e.get("grid_threads") not in (want, 8 * want, 65 * want):       # one-XCD launches use an 8x oversubscribed grid; the one-workgroup fp64 launch brings 64 helper blocks
+        g_ = e.get("grid_threads") or 0
+        helpers = want > 0 and g_ % want == 0 and (g_ // want - 1) % 8 == 0    # one-workgroup launches of ONE system bring 8 x h helper blocks
+        if g_ not in (want, 8 * want) and not helpers:                      # one-XCD launches use an 8x oversubscribed grid
             return None, f"stale: collected on a grid of {e.get('grid_threads')} threads, this run launched {want}"
         single = ("pcg_single_f32x2" in k and fam == "float") or ("pcg_single_f64m" in k and fam == "double")
         if not single and (fam + ", " + str(res["S"])) not in k:

@@ -894,10 +894,10 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
             a.dz_Ginv = s->fz.Ginv; a.dz_Cd = s->fz.Cd; a.dz_g = s->fz.g; a.dz = s->fz.dz; a.C = s->d.C;
             s->dz_fused = 1;
         }
-        // ONE system through the one-workgroup fp64 kernel (pcg_single_f64m_kernel, BASELINE configs[1]): its helper blocks - there
+        // ONE system through a two-rows-per-lane one-workgroup kernel (pcg_single_f64m_kernel = BASELINE configs[1]; pcg_single_f32x2_kernel): its helper blocks - there
         // to warm the L2 - stay and do dz as soon as lambda is published: the dz launch and the gap in front of it (6.5 us of a
         // 215 us step) become ~1 us at the end of the PCG launch.  no_fuse_dz = 1 keeps the launch of its own.
-        else if (s->fz.dz && !s->no_fuse_dz && batch == 1 && groups == 1 && !cg1 && s->plan_pair == 2 && !s->stamp_pcg && !s->tuning) {
+        else if (s->fz.dz && !s->no_fuse_dz && batch == 1 && groups == 1 && !cg1 && (s->plan_pair == 2 || s->plan_pair == 1) && !s->stamp_pcg && !s->tuning) {
             a.dz_Ginv = s->fz.Ginv; a.dz_Cd = s->fz.Cd; a.dz_g = s->fz.g; a.dz = s->fz.dz; a.C = s->d.C;
             a.dz_helpers = 1; a.dz_flag = s->dz_flag;
             s->dz_fused = 2;

@@ -1148,6 +1148,100 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
     }
 }
 
+// Helper blocks of the ONE-SYSTEM launches of the one-workgroup kernels (gridDim = 1 + 8 x helpers; block 0 solves).  Called by
+// every block but block 0; `scratch`: LDS, (4 S^2 + 6 S) values per wave of the block.
+template <typename T, int S>
+__device__ __forceinline__ void one_system_helper(const PcgLaunch &a, T *scratch)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockDim.x, nwv = nt >> 6, K = a.K;
+    if ((blockIdx.x & 7) != 0) return;
+    const size_t h = (blockIdx.x >> 3) - 1, nh = (gridDim.x - 1) >> 3;
+    const size_t lines = ((size_t)3 * S * S * K * sizeof(T) + 127) / 128;
+    typedef int I4 __attribute__((ext_vector_type(4)));
+    const I4 *s4 = static_cast<const I4 *>(a.S_bd), *p4 = static_cast<const I4 *>(a.P_bd);
+    const size_t last16 = (size_t)3 * S * S * K * sizeof(T) / 16 - 1;         // last whole 16-byte unit of an array
+    I4 acc = {0, 0, 0, 0};
+    for (size_t l = h * nt + tid; l < lines; l += nh * nt) {
+        const size_t u = l * 8 < last16 ? l * 8 : last16;
+        acc ^= s4[u] ^ p4[u];
+    }
+    asm volatile("" ::"v"(acc));
+    // ... and then stay for the dz back-substitution (compute_dz, gato_schur.cuh:758-867): wave w of helper h takes knot
+    // h * WT + w, brings Q_k^-1, R_k^-1, A_k, B_k and g_k into LDS while the solve runs, waits (sleeping) until the solving
+    // workgroup has stored launch_id in *dz_flag - lambda is complete and released - and finishes in about a microsecond.
+    // That replaces a launch of its own (5.3 us + the gap in front of it) at the end of every step.  Formulas and
+    // accumulation order of dz_kernel (gato_assembly.hip), row by row: the same bits.  The solving workgroup never waits for
+    // a helper, so helpers that are scheduled late (or after it has finished) just find the flag set.
+    if (a.dz_helpers && a.dz != nullptr) {
+        const int kq = (int)h * nwv + wave;
+        if (kq >= K) return;
+        const int Cn = a.C, n = S + Cn, SS = S * S;
+        const size_t gs = (size_t)(SS + Cn * Cn), cs = (size_t)(SS + S * Cn);
+        const T *__restrict__ Qg = static_cast<const T *>(a.dz_Ginv) + (size_t)kq * gs;
+        const T *__restrict__ Ag = static_cast<const T *>(a.dz_Cd) + (size_t)kq * cs;
+        const T *__restrict__ gg = static_cast<const T *>(a.dz_g) + (size_t)kq * n;
+        const T *__restrict__ lg = static_cast<const T *>(a.lambda) + (size_t)kq * S;
+        T *__restrict__ dzo = static_cast<T *>(a.dz) + (size_t)kq * n;
+        const bool last = kq == K - 1;
+        T *scr = scratch + (size_t)wave * (4 * SS + 6 * S);                                   // this wave's own part of the LDS
+        T *sQi = scr, *sA = sQi + SS, *sRi = sA + SS, *sB = sRi + SS, *sl = sB + SS, *st = sl + 2 * S, *sg = st + 2 * S;
+        for (int i = lane; i < SS; i += 64) sQi[i] = Qg[i];
+        for (int i = lane; i < (last ? S : n); i += 64) sg[i] = gg[i];
+        if (!last) {
+            for (int i = lane; i < Cn * Cn; i += 64) sRi[i] = Qg[SS + i];
+            for (int i = lane; i < SS; i += 64) sA[i] = Ag[i];
+            for (int i = lane; i < S * Cn; i += 64) sB[i] = Ag[SS + i];
+        }
+        gi32 *flag = (gi32 *)a.dz_flag;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool late = false;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.launch_id) {
+            __builtin_amdgcn_s_sleep(4);                      // ~0.1 us between looks: 50 waves, one load each
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { late = true; break; }
+        }
+        if (late) {         // cannot happen unless the solving workgroup died: report it like a hand-off time-out
+            if (lane == 0) __hip_atomic_store((gi32 *)a.status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int i = lane; i < (last ? S : 2 * S); i += 64) sl[i] = __hip_atomic_load(lg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wave_lds_fence();
+        if (!last) {
+            for (int i = lane; i < S; i += 64) {                                  // A_k^T lambda_{k+1}   :833-838
+                T res = (T)0;
+#pragma unroll
+                for (int t = 0; t < S; ++t) res = gato::fmaT(sA[i * S + t], sl[S + t], res);
+                st[i] = res;
+            }
+            for (int i = lane; i < Cn; i += 64) {                                 // B_k^T lambda_{k+1}   :784-789
+                T res = (T)0;
+#pragma unroll
+                for (int t = 0; t < S; ++t) res = gato::fmaT(sB[i * S + t], sl[S + t], res);
+                st[S + i] = res;
+            }
+            wave_lds_fence();
+            for (int i = lane; i < S; i += 64) st[i] = sg[i] - (sl[i] + st[i]);                    // :841-852
+            for (int i = lane; i < Cn; i += 64) st[S + i] = sg[S + i] - st[S + i];                 // :792-796
+        } else {
+            for (int i = lane; i < S; i += 64) st[i] = sg[i] - sl[i];             // last state row (D2)
+        }
+        wave_lds_fence();
+        for (int r = lane; r < S; r += 64) {                                      // Q_k^-1 (...)         :856-865
+            T res = (T)0;
+#pragma unroll
+            for (int cc = 0; cc < S; ++cc) res = gato::fmaT(sQi[r + cc * S], st[cc], res);
+            dzo[r] = res;
+        }
+        if (!last) {
+            for (int r = lane; r < Cn; r += 64) {                                 // R_k^-1 (...)         :799-808
+                T res = (T)0;
+                for (int cc = 0; cc < Cn; ++cc) res = gato::fmaT(sRi[r + cc * Cn], st[S + cc], res);
+                dzo[S + r] = res;
+            }
+        }
+    }
+}
+
 // ---- fp32, one workgroup (or one workgroup per system of a batch), TWO rows per lane --------------------------
 // The single-workgroup loop is instruction-issue bound: with two rows of the same knot per lane
 // the operand-window reads are shared by both rows, the FMAs pair up as v_pk_fma_f32 and the wave count halves
@@ -1166,6 +1260,12 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int K = a.K;
+    // one system: helper blocks (L2 warm-up of S and Pinv, then dz) as in pcg_single_f64m_kernel
+    __shared__ __attribute__((aligned(16))) float hscr[(MAXT / 64) * (4 * S * S + 6 * S)];
+    if (a.batch <= 1 && blockIdx.x > 0) {
+        one_system_helper<float, S>(a, hscr);
+        return;
+    }
     const size_t sys = a.batch > 1 ? blockIdx.x : 0;
     const int j = tid / H, h = tid - j * H;        // knot, row pair (2h, 2h + 1): adjacent, so every matrix column is ONE 8-byte load
     const bool active = j < K;                     // (pairs (h, h + H) cost two scattered 4-byte loads per column: 10 us per launch)
@@ -1260,6 +1360,11 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         __syncthreads();
     }
     if (active) { dL[(size_t)j * S + r0] = lam[0]; dL[(size_t)j * S + r1] = lam[1]; }
+    if (a.dz_helpers && a.dz != nullptr && a.batch <= 1) {       // lambda is complete: release it and tell the helper blocks
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store((gi32 *)a.dz_flag, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (tid == 0) {
         a.iters[sys] = iters;
         if (a.final_eta && sys == 0) *a.final_eta = (double)eta_new;
@@ -1303,93 +1408,8 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
     // thread one line per array, and leave; the solving workgroup's loads then find the lines in that XCD's L2 or merge with
     // the misses in flight.  A speed hint only: wherever the blocks really run, nothing read or written depends on it.
     if (a.batch <= 1 && blockIdx.x > 0) {
-        if ((blockIdx.x & 7) != 0) return;
-        const size_t h = (blockIdx.x >> 3) - 1, nh = (gridDim.x - 1) >> 3;
-        const size_t lines = ((size_t)3 * S * S * K * sizeof(T) + 127) / 128;
-        typedef int I4 __attribute__((ext_vector_type(4)));
-        const I4 *s4 = static_cast<const I4 *>(a.S_bd), *p4 = static_cast<const I4 *>(a.P_bd);
-        const size_t last16 = (size_t)3 * S * S * K * sizeof(T) / 16 - 1;         // last whole 16-byte unit of an array
-        I4 acc = {0, 0, 0, 0};
-        for (size_t l = h * NT + tid; l < lines; l += nh * NT) {
-            const size_t u = l * 8 < last16 ? l * 8 : last16;
-            acc ^= s4[u] ^ p4[u];
-        }
-        asm volatile("" ::"v"(acc));
-        // ... and then stay for the dz back-substitution (compute_dz, gato_schur.cuh:758-867): wave w of helper h takes knot
-        // h * WT + w, brings Q_k^-1, R_k^-1, A_k, B_k and g_k into LDS while the solve runs, waits (sleeping) until the solving
-        // workgroup has stored launch_id in *dz_flag - lambda is complete and released - and finishes in about a microsecond.
-        // That replaces a launch of its own (5.3 us + the gap in front of it) at the end of every step.  Formulas and
-        // accumulation order of dz_kernel (gato_assembly.hip), row by row: the same bits.  The solving workgroup never waits for
-        // a helper, so helpers that are scheduled late (or after it has finished) just find the flag set.
-        if (a.dz_helpers && a.dz != nullptr) {
-            const int kq = (int)h * WT + wave;
-            if (kq >= K) return;
-            const int Cn = a.C, n = S + Cn, SS = S * S;
-            const size_t gs = (size_t)(SS + Cn * Cn), cs = (size_t)(SS + S * Cn);
-            const T *__restrict__ Qg = static_cast<const T *>(a.dz_Ginv) + (size_t)kq * gs;
-            const T *__restrict__ Ag = static_cast<const T *>(a.dz_Cd) + (size_t)kq * cs;
-            const T *__restrict__ gg = static_cast<const T *>(a.dz_g) + (size_t)kq * n;
-            const T *__restrict__ lg = static_cast<const T *>(a.lambda) + (size_t)kq * S;
-            T *__restrict__ dzo = static_cast<T *>(a.dz) + (size_t)kq * n;
-            const bool last = kq == K - 1;
-            T *scr = reinterpret_cast<T *>(&ptail[0][0]) + (size_t)wave * (4 * SS + 6 * S);       // this wave's own part of the LDS
-            T *sQi = scr, *sA = sQi + SS, *sRi = sA + SS, *sB = sRi + SS, *sl = sB + SS, *st = sl + 2 * S, *sg = st + 2 * S;
-            static_assert((size_t)WT * (4 * S * S + 6 * S) * sizeof(T) <= sizeof(ptail), "dz scratch of the helper waves");
-            for (int i = lane; i < SS; i += 64) sQi[i] = Qg[i];
-            for (int i = lane; i < (last ? S : n); i += 64) sg[i] = gg[i];
-            if (!last) {
-                for (int i = lane; i < Cn * Cn; i += 64) sRi[i] = Qg[SS + i];
-                for (int i = lane; i < SS; i += 64) sA[i] = Ag[i];
-                for (int i = lane; i < S * Cn; i += 64) sB[i] = Ag[SS + i];
-            }
-            gi32 *flag = (gi32 *)a.dz_flag;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            bool late = false;
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.launch_id) {
-                __builtin_amdgcn_s_sleep(4);                      // ~0.1 us between looks: 50 waves, one load each
-                if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { late = true; break; }
-            }
-            if (late) {         // cannot happen unless the solving workgroup died: report it like a hand-off time-out
-                if (lane == 0) __hip_atomic_store((gi32 *)a.status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            for (int i = lane; i < (last ? S : 2 * S); i += 64) sl[i] = __hip_atomic_load(lg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            wave_lds_fence();
-            if (!last) {
-                for (int i = lane; i < S; i += 64) {                                  // A_k^T lambda_{k+1}   :833-838
-                    T res = (T)0;
-#pragma unroll
-                    for (int t = 0; t < S; ++t) res = gato::fmaT(sA[i * S + t], sl[S + t], res);
-                    st[i] = res;
-                }
-                for (int i = lane; i < Cn; i += 64) {                                 // B_k^T lambda_{k+1}   :784-789
-                    T res = (T)0;
-#pragma unroll
-                    for (int t = 0; t < S; ++t) res = gato::fmaT(sB[i * S + t], sl[S + t], res);
-                    st[S + i] = res;
-                }
-                wave_lds_fence();
-                for (int i = lane; i < S; i += 64) st[i] = sg[i] - (sl[i] + st[i]);                    // :841-852
-                for (int i = lane; i < Cn; i += 64) st[S + i] = sg[S + i] - st[S + i];                 // :792-796
-            } else {
-                for (int i = lane; i < S; i += 64) st[i] = sg[i] - sl[i];             // last state row (D2)
-            }
-            wave_lds_fence();
-            for (int r = lane; r < S; r += 64) {                                      // Q_k^-1 (...)         :856-865
-                T res = (T)0;
-#pragma unroll
-                for (int cc = 0; cc < S; ++cc) res = gato::fmaT(sQi[r + cc * S], st[cc], res);
-                dzo[r] = res;
-            }
-            if (!last) {
-                for (int r = lane; r < Cn; r += 64) {                                 // R_k^-1 (...)         :799-808
-                    T res = (T)0;
-                    for (int cc = 0; cc < Cn; ++cc) res = gato::fmaT(sRi[r + cc * Cn], st[S + cc], res);
-                    dzo[S + r] = res;
-                }
-            }
-        }
+        static_assert((size_t)WT * (4 * S * S + 6 * S) * sizeof(T) <= sizeof(ptail), "dz scratch of the helper waves");
+        one_system_helper<T, S>(a, reinterpret_cast<T *>(&ptail[0][0]));
         return;
     }
     const size_t sys = a.batch > 1 ? blockIdx.x : 0;
@@ -1803,7 +1823,9 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
                 return GATO_EINVAL;
             }
             if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-            hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT>), dim3(a.batch > 1 ? a.batch : 1), dim3(a.threads), 0, st, a);
+            // one system: + helper blocks (enough waves for one knot each: they also do dz), see pcg_single_f64m_kernel
+            const int helpers = (a.K + a.threads / 64 - 1) / (a.threads / 64);
+            hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT>), dim3(a.batch > 1 ? a.batch : 1 + 8 * helpers), dim3(a.threads), 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;

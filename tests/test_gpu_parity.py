@@ -1238,32 +1238,34 @@ def test_stage_times_as_data():
     sol.close()
 
 
-@pytest.mark.parametrize("K", [50, 41, 37])
-def test_dz_by_the_helper_blocks_is_bit_identical_to_the_dz_launch(K):
-    """BASELINE configs[1] (one system, fp64, the mixed-rows kernel): the launch's helper blocks - there to warm the L2 - also do
-    the dz back-substitution as soon as the solving workgroup has published lambda (default; no_fuse_dz = 1 keeps the dz launch).
-    Same formulas and order as dz_kernel: the same bits, run after run."""
+@pytest.mark.parametrize("K,dt", [(50, np.float64), (41, np.float64), (37, np.float64), (50, np.float32), (73, np.float32), (9, np.float32)])
+def test_dz_by_the_helper_blocks_is_bit_identical_to_the_dz_launch(K, dt):
+    """BASELINE configs[1] (one system, fp64, the mixed-rows kernel) and the fp32 two-rows-per-lane kernel: the launch's helper
+    blocks - there to warm the L2 - also do the dz back-substitution as soon as the solving workgroup has published lambda
+    (default; no_fuse_dz = 1 keeps the dz launch).  Same formulas and order as dz_kernel: the same bits, run after run."""
     from gato_python_amd.solver import Solver
     S, C = 14, 7
     s = system(S, C, K, seed=7)
     res = {}
+    f64 = dt == np.float64
+    tol = 1e-9 if f64 else 1e-5
     for nofuse in (0, 1):
-        sol = Solver(S, C, K, np.float64)
+        sol = Solver(S, C, K, dt)
         sol.set_option("no_fuse_dz", nofuse)
         dev = sol.upload_system(s)
         lam, dz = sol.new(S * K), sol.new(sol.N)
         runs = []
         for rep in range(6):
             dz.fill_(float("nan"))
-            sol.linsys(*dev, 1e-9, 80, s.rho, lam, dz)
+            sol.linsys(*dev, tol, 80, s.rho, lam, dz)
             sol.check_status()
             runs.append((host(lam).copy(), host(dz).copy()))
-        assert sol.get_option("last_dz_fused") == (0 if nofuse else 2) and sol.get_option("last_pair") == 2
+        assert sol.get_option("last_dz_fused") == (0 if nofuse else 2) and sol.get_option("last_pair") == (2 if f64 else 1)
         assert all(np.array_equal(r[0], runs[0][0]) and np.array_equal(r[1], runs[0][1]) for r in runs)
         res[nofuse] = runs[0]
         sol.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
-    check_solve(f"dz by the helper blocks 14/7/{K}", s, S, C, K, np.float64, 1e-9, 80, res[0][0], res[0][1], f64_tol=1e-9)
+    check_solve(f"dz by the helper blocks 14/7/{K} {np.dtype(dt).name}", s, S, C, K, dt, tol, 80, res[0][0], res[0][1], f64_tol=1e-9)
 
 
 @pytest.mark.parametrize("S,C,K,dt,B", [(14, 7, 50, np.float64, 1), (14, 7, 37, np.float64, 1), (14, 7, 50, np.float64, 6), (2, 1, 5, np.float64, 1),

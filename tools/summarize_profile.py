@@ -100,8 +100,9 @@ WL["iiwa_14_7_k16384_f32"] = ("pcg_resident_kernel<float, 14", 16384)
 
 for name, (prefix, K) in WL.items():
     for key in fetch:
-        if key[0].startswith(prefix) and geom.get(name) in (key[1], key[1] // 8 if key[1] % 8 == 0 else -1,      # xcd_pack launches an 8x grid;
-                                                            key[1] // 65 if key[1] % 65 == 0 else -1):   # the one-workgroup fp64 launch brings 64 helper blocks
+        want = geom.get(name) or 0
+        helpers = "pcg_single_" in key[0] and want > 0 and key[1] % want == 0 and (key[1] // want - 1) % 8 == 0 and key[1] // want < 200   # + 8 x h helper blocks
+        if key[0].startswith(prefix) and (want in (key[1], key[1] // 8 if key[1] % 8 == 0 else -1) or helpers):   # xcd_pack launches an 8x grid
             fv, wv = fetch[key], write.get(key, [])
             if ", 16, false" in key[0] and ("iiwa_14_7_k16384_f32" in geom and "iiwa_14_7_k131072_f32_semi" in geom):
                 big = name == "iiwa_14_7_k131072_f32_semi"
