@@ -182,6 +182,7 @@ struct gato_solver {
     int dz_fused;                     // the most recent PCG launch also did the dz back-substitution (1: in the solving workgroup, 2: in helper blocks)
     int *dz_flag;                     // device word for the helper blocks of the one-workgroup fp64 launch
     int no_fuse_dz;                   // option
+    int shared_windows;               // option: one-workgroup kernels with shared operand windows (the four-barrier form)
     unsigned long long **cl_tab;      // device copy of cl.peer (the kernel reads the peers' mirror addresses from it)
 };
 
@@ -479,6 +480,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "timeout_ms")) s->timeout_ms = value > 0 ? value : 2000;
     else if (!strcmp(name, "max_workgroups")) s->max_workgroups = value;
     else if (!strcmp(name, "no_fuse_dz")) s->no_fuse_dz = value;
+    else if (!strcmp(name, "shared_windows")) s->shared_windows = value;
     else if (!strcmp(name, "cluster_flat")) s->cluster_flat = value;
     else if (!strcmp(name, "knot_lo") || !strcmp(name, "knot_hi")) {          // stage-level entries: knots [knot_lo, knot_hi)
         if (value < 0 || value > s->d.K) { set_error("%s = %d is outside [0, %d]", name, value, s->d.K); return GATO_EINVAL; }
@@ -855,6 +857,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.K = s->d.K; a.max_iters = max_iters; a.exit_tol = exit_tol;
         a.batch = batch;
         a.pair = s->plan_pair;
+        a.shared_windows = s->shared_windows;
         a.semi = cg1 ? 0 : s->plan_semi;
         a.dpp_rows = cg1 ? 0 : s->plan_dpp;
         // option xcd_pack: -1 = auto (default): up to 32 workgroups are placed on ONE XCD (measured 15-20 % faster hand-offs:

@@ -16,8 +16,10 @@
 #define GATO_EXTRA_SHAPES(X)
 #endif
 // default build: pendulum (2/1, the reference's test), IIWA-14 (14/7, its default), 32/16 (BASELINE config 5) and a few
-// common robot sizes
+// common robot sizes (tools/devbuild.sh predefines GATO_SHAPES with fewer shapes for a quick A/B library)
+#ifndef GATO_SHAPES
 #define GATO_SHAPES(X) X(2, 1) X(14, 7) X(32, 16) X(4, 2) X(6, 3) X(12, 6) GATO_EXTRA_SHAPES(X)
+#endif
 
 #define GATO_MAX_RANKS 8     /* GPUs of one node a cluster launch spans (gato_cluster_*) */
 
@@ -157,6 +159,7 @@ struct PcgLaunch {
     double exit_tol;
     int batch;                   // > 1: blockIdx.x = system index, one workgroup per system (groups must be 1)
     int pair;                    // fp32 one-workgroup kernel with two rows per lane
+    int shared_windows;          // one-workgroup two-rows-per-lane kernels: 1 = shared operand windows (four barriers per iteration) instead of wave-private ones
     int xcd_pack;                // 2..32 workgroups: place them on one XCD (grid 8x oversubscribed, 7 of 8 blocks exit)
     int xcd_sel;                 // 0..7: the XCD (blockIdx % 8) that hosts them
     int wave_pub;                // launches of 2..32 workgroups: every wave publishes its own partial (no gather barrier); 0 = gathered form

@@ -1248,7 +1248,18 @@ __device__ __forceinline__ void one_system_helper(const PcgLaunch &a, T *scratch
 // (IIWA 14/7/50: 6 waves instead of 11), and the one-CU regime extends to K*S <= 2*MAXT rows.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int S, int MAXT>
+// PW (round 3, what production runs): WAVE-PRIVATE operand windows.  In the shared-window form an iteration has four
+// barriers: two inside the block sums and two between a vector update and the product that reads the updated window (every
+// lane must have stored its entries of r / p before any lane reads its neighbours').  With PW every wave keeps its OWN copy of
+// the part of the r and p windows its lanes read - its own 128 rows plus a halo of up to 2S - 1 rows on either side - and
+// advances the halo rows itself: up to 4S - 2 lanes of the wave hold one halo row of r and p in a register, fetch that row's
+// entry of upsilon (of r~) from a shared exchange window which the owners fill BEFORE the block sum's barrier, and apply the
+// owner's own FMA (r - alpha upsilon, r~ + beta p: the same bits, tools/pw_check.py and test_private_windows_*).  A wave then
+// reads only LDS words it wrote itself (LDS operations of one wave execute in order: no barrier, no wait), so the two window
+// barriers and the LDS write latency in front of them are gone: two barriers per iteration.  14/7/50 fp32: 1.405 -> 1.340 us
+// per iteration (with 14 spilled VGPRs).  The fp64 mixed-rows kernel gains nothing from it (its loop is bound by the LDS read
+// queue, not by barriers: measured 1.945 us with two barriers and no halo update at all against 1.94) and keeps shared windows.
+template <int S, int MAXT, bool PW = false>
 __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
 {
     constexpr int H = S / 2;                       // lanes per knot
@@ -1257,6 +1268,10 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
     static_assert(S % 2 == 0, "two rows per lane need an even STATE_SIZE");
     __shared__ __attribute__((aligned(16))) float xs[2][(MAXK + 2) * SP];
     __shared__ __attribute__((aligned(16))) float wpart[2][4 * ((MAXT + 63) / 64)];
+    constexpr int PK = (128 - 1 + S - 1) / S + 1 + 2;                 // knots a wave's 128 rows can span + a halo knot on either side
+    constexpr int PWLEN = PW ? (MAXT / 64) * PK * SP : 4;
+    static_assert(!PW || 4 * S - 2 <= 64, "private windows: one halo row per lane");
+    __shared__ __attribute__((aligned(16))) float pwin[2][PWLEN];     // PW: [0] = p, [1] = r, wave after wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int K = a.K;
@@ -1291,7 +1306,28 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         }
     }
     for (int i = tid; i < 2 * (MAXK + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = 0.f;
+    if constexpr (PW)
+        for (int i = tid; i < 2 * PWLEN; i += blockDim.x) (&pwin[0][0])[i] = 0.f;
     __syncthreads();
+    // PW: the wave's rows [R0, R1), its private windows (slot 0 = knot jf - 1) and the lane's halo row
+    int hoff = 0, hpo = 0, own_po = 0, win_po = 0;
+    bool hvalid = false;
+    float *pw_p = nullptr, *pw_r = nullptr;
+    if constexpr (PW) {
+        const int R0 = 128 * wave, R1 = min(R0 + 128, K * S);
+        pw_p = &pwin[0][wave * PK * SP]; pw_r = &pwin[1][wave * PK * SP];
+        if (R0 < R1) {
+            const int jf = R0 / S, jl = (R1 - 1) / S, base_row = (jf - 1) * S;
+            const int nb = R0 - base_row, na = (jl + 2) * S - R1;
+            const int hrow = lane < nb ? base_row + lane : R1 + (lane - nb);
+            hvalid = lane < nb + na && hrow >= 0 && hrow < K * S;
+            const int hj = hvalid ? hrow / S : 0, hr = hvalid ? hrow - hj * S : 0;
+            hoff = hvalid ? (hj + 1) * SP + hr : 0;
+            hpo = hvalid ? (hj - jf + 1) * SP + hr : 0;
+            own_po = active ? (j - jf + 1) * SP + r0 : 0;
+            win_po = active ? (j - jf) * SP : 0;
+        }
+    }
 
     auto times_window = [&](const f32x2 (&m)[3 * S], const float *xw) -> f32x2 {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1320,6 +1356,21 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         if (active) *reinterpret_cast<f32x2 *>(buf + (j + 1) * SP + r0) = v;
     };
 
+    const float *wp_ = PW ? pw_p + win_po : &xs[0][j * SP], *wr_ = PW ? pw_r + win_po : &xs[1][j * SP];
+    auto put_private = [&](float *pw, f32x2 v, float g) {
+        if (active) *reinterpret_cast<f32x2 *>(pw + own_po) = v;
+        if (hvalid) pw[hpo] = g;
+        wave_lds_fence();
+    };
+    auto block_sum_x = [&](float prod, const float *xw, float &hx) -> float {
+        ++epoch;
+        float *wp = wpart[epoch & 1];
+        partials_store(wp, wave, lane, prod);
+        __syncthreads();
+        hx = xw[hoff];
+        return partials_total<float, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
+    };
+
     f32x2 lam = {0.f, 0.f};
     f32x2 r = active ? f32x2{dG[(size_t)j * S + r0], dG[(size_t)j * S + r1]} : f32x2{0.f, 0.f};
     if (a.lambda0) {                                                       // true warm start (opt-in)
@@ -1330,34 +1381,68 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         r -= times_window(sm, &xs[0][j * SP]);
         __syncthreads();
     }
-    put(xs[1], r);
-    __syncthreads();
-    f32x2 rt = times_window(pm, &xs[1][j * SP]);                          // gato_pcg.cuh:316-335
-    float eta = block_sum(r[0] * rt[0] + r[1] * rt[1]), eta_new = 0.f;
+    float gr = 0.f, gp = 0.f;                                              // PW: r and p of the lane's halo row
+    if constexpr (PW) {
+        put(xs[0], r);
+        __syncthreads();
+        gr = hvalid ? xs[0][hoff] : 0.f;
+        put_private(pw_r, r, gr);
+    } else {
+        put(xs[1], r);
+        __syncthreads();
+    }
+    f32x2 rt = times_window(pm, wr_);                                      // gato_pcg.cuh:316-335
+    float eta, eta_new = 0.f;
+    if constexpr (PW) {
+        put(xs[1], rt);
+        eta = block_sum_x(r[0] * rt[0] + r[1] * rt[1], xs[1], gp);
+    } else eta = block_sum(r[0] * rt[0] + r[1] * rt[1]);
     const bool rec = a.eta_hist && tid == 0 && sys == 0;
     if (rec) a.eta_hist[0] = (double)eta;
     f32x2 p = rt, ups;
-    put(xs[0], p);
-    __syncthreads();
+    if constexpr (PW) put_private(pw_p, p, gp);
+    else {
+        put(xs[0], p);
+        __syncthreads();
+    }
     int iters = a.max_iters;
     const float tol = (float)a.exit_tol;
     for (int it = 0; it < a.max_iters; ++it) {                             // gato_pcg.cuh:348
-        ups = times_window(sm, &xs[0][j * SP]);
-        const float v = block_sum(p[0] * ups[0] + p[1] * ups[1]);
+        ups = times_window(sm, wp_);
+        float v, hx = 0.f;
+        if constexpr (PW) {
+            put(xs[0], ups);
+            v = block_sum_x(p[0] * ups[0] + p[1] * ups[1], xs[0], hx);
+        } else v = block_sum(p[0] * ups[0] + p[1] * ups[1]);
         const float alpha = quotient(eta, v);
         lam += alpha * p;
         r -= alpha * ups;
-        put(xs[1], r);
-        __syncthreads();
-        rt = times_window(pm, &xs[1][j * SP]);
-        eta_new = block_sum(r[0] * rt[0] + r[1] * rt[1]);
+        if constexpr (PW) {
+            gr -= alpha * hx;
+            asm volatile("" : "+v"(gr) : : "memory");      // the halo value first: no wait for hx BETWEEN the two LDS writes
+            put_private(pw_r, r, gr);
+        } else {
+            put(xs[1], r);
+            __syncthreads();
+        }
+        rt = times_window(pm, wr_);
+        if constexpr (PW) {
+            put(xs[1], rt);
+            eta_new = block_sum_x(r[0] * rt[0] + r[1] * rt[1], xs[1], hx);
+        } else eta_new = block_sum(r[0] * rt[0] + r[1] * rt[1]);
         if (rec) a.eta_hist[it + 1] = (double)eta_new;
         if (fabsf(eta_new) < tol) { iters = it; break; }                   // :404-411
         const float beta = quotient(eta_new, eta);
         p = rt + beta * p;
-        put(xs[0], p);
         eta = eta_new;
-        __syncthreads();
+        if constexpr (PW) {
+            gp = hx + beta * gp;
+            asm volatile("" : "+v"(gp) : : "memory");
+            put_private(pw_p, p, gp);
+        } else {
+            put(xs[0], p);
+            __syncthreads();
+        }
     }
     if (active) { dL[(size_t)j * S + r0] = lam[0]; dL[(size_t)j * S + r1] = lam[1]; }
     if (a.dz_helpers && a.dz != nullptr && a.batch <= 1) {       // lambda is complete: release it and tell the helper blocks
@@ -1825,7 +1910,9 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
             if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
             // one system: + helper blocks (enough waves for one knot each: they also do dz), see pcg_single_f64m_kernel
             const int helpers = (a.K + a.threads / 64 - 1) / (a.threads / 64);
-            hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT>), dim3(a.batch > 1 ? a.batch : 1 + 8 * helpers), dim3(a.threads), 0, st, a);
+            const dim3 grid(a.batch > 1 ? a.batch : 1 + 8 * helpers);
+            if (a.shared_windows) hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT, false>), grid, dim3(a.threads), 0, st, a);
+            else hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT, true>), grid, dim3(a.threads), 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;

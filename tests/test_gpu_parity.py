@@ -1268,6 +1268,46 @@ def test_dz_by_the_helper_blocks_is_bit_identical_to_the_dz_launch(K, dt):
     check_solve(f"dz by the helper blocks 14/7/{K} {np.dtype(dt).name}", s, S, C, K, dt, tol, 80, res[0][0], res[0][1], f64_tol=1e-9)
 
 
+@pytest.mark.parametrize("K,B,warm", [(50, 1, 0), (73, 1, 0), (49, 1, 1), (19, 1, 0), (10, 1, 1), (9, 1, 0), (2, 1, 0), (1, 1, 0), (50, 5, 0), (23, 7, 0)])
+def test_private_windows_give_the_bits_of_the_shared_windows(K, B, warm):
+    """The fp32 two-rows-per-lane kernel (the reference's precision at its own shape: what the drop-in runs at 14/7/50) keeps
+    WAVE-PRIVATE operand windows: every wave advances the halo rows of r and p itself with the owner's FMA, so the two window
+    barriers of an iteration are gone (default).  shared_windows = 1 is the four-barrier form: the same lambda, dz and
+    iteration count bit for bit - wave boundaries inside a knot (K = 19, 73), one- and two-knot systems, true warm start,
+    batches - and the default meets the oracle."""
+    from gato_python_amd.solver import Solver
+    S, C, dt = 14, 7, np.float32
+    systems = [system(S, C, K, seed=11 + b) if K > 1 else synth.blocks_to_csr(*synth.make_blocks(S, C, 1, 11 + b, False)) for b in range(B)]
+    res = {}
+    for shared in (0, 1):
+        sol = Solver(S, C, K, dt, batch=B)
+        sol.set_option("shared_windows", shared)
+        if warm:
+            sol.set_option("true_warm_start", 1)
+        sol.set_option("record_eta", 1)
+        lam, dz, it = sol.new(B * S * K), sol.new(B * sol.N), sol.new(B, torch.int32)
+        dev = sol.upload_batch(systems) if B > 1 else sol.upload_system(systems[0])
+        runs = []
+        for (tol, mi) in ((0.0, 12 if K > 2 else K), (1e-5, 80)):     # (a one-knot system is solved exactly by its first step: eta = 0 afterwards)
+            if warm:
+                lam.copy_(torch.from_numpy(np.random.default_rng(K).standard_normal(B * S * K).astype(dt)))
+            if B > 1:
+                sol.linsys_batched(*dev, tol, mi, systems[0].rho, lam, dz, it)
+            else:
+                sol.linsys(*dev, tol, mi, systems[0].rho, lam, dz)
+            sol.check_status()
+            runs.append((host(lam).copy(), host(dz).copy(), host(it).copy() if B > 1 else sol.eta_history(min(mi, 12))))
+        assert sol.get_option("last_pair") == 1 and sol.get_option("last_groups") == 1
+        res[shared] = runs
+        sol.close()
+    for a, b in zip(res[0], res[1]):
+        assert np.isfinite(a[0]).all() and np.isfinite(a[1]).all()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    if not warm and K > 2:
+        n_dz = (S + C) * K - C
+        check_solve(f"private windows 14/7/{K} x{B} float32", systems[0], S, C, K, dt, 1e-5, 80, res[0][1][0][:S * K], res[0][1][1][:n_dz])
+
+
 @pytest.mark.parametrize("S,C,K,dt,B", [(14, 7, 50, np.float64, 1), (14, 7, 37, np.float64, 1), (14, 7, 50, np.float64, 6), (2, 1, 5, np.float64, 1),
                                         (32, 16, 7, np.float32, 1), (14, 7, 1, np.float64, 1), (14, 7, 2, np.float32, 3)])
 def test_dz_in_the_pcg_epilogue_is_bit_identical_to_the_dz_launch(S, C, K, dt, B):
