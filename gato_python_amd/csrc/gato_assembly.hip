@@ -529,6 +529,13 @@ __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStr
     T *Gd = (T *)a.Gd + sys * bs.g, *Cd = (T *)a.Cd + sys * bs.c, *Ginv = (T *)a.Ginv + sys * bs.g;
     T *Sbd = (T *)a.Sbd + sys * bs.bd, *Pbd = (T *)a.Pbd + sys * bs.bd, *gamma = (T *)a.gamma + sys * bs.sk;
     const T rho = (T)a.rho;
+    // optional second copy of S and Pinv for the one-workgroup PCG kernels (PcgLaunch::imgS): entry (row r of knot kk, column
+    // cc of block b) at img[(b S + cc) ld + kk S + r] - a lane of those kernels then loads its 3S entries with unit stride
+    // across the wave.  One system only (the caller passes nullptr otherwise).
+    T *const iS = (T *)a.imgS, *const iP = (T *)a.imgP;
+    const size_t ild = (size_t)a.img_ld;
+    auto imS = [&](int kk, int b, int r, int cc, T v) { if (iS) iS[(size_t)(b * S + cc) * ild + (size_t)kk * S + r] = v; };
+    auto imP = [&](int kk, int b, int r, int cc, T v) { if (iP) iP[(size_t)(b * S + cc) * ild + (size_t)kk * S + r] = v; };
     // this knot's operands (sub-knot 1) and the previous knot's (sub-knot 0)
     T *sQk = sQ + 2 * SS, *sRk = sR + 2 * CC, *sQm = sQ + SS, *sRm = sR + CC, *sQmm = sQ, *sRmm = sR;
     T *sA1 = sAB + ABS, *sB1 = sA1 + SS, *sA0 = sAB, *sB0 = sAB + SS;
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStr
             if (!last) for (int i = tid; i < CC; i += NT) Gd[gk + SS + i] = sRk[i];
             if (a.mode == 0 && !first) for (int i = tid; i < ABS; i += NT) Cd[cm + i] = sA1[i];
         }
-        if (first) for (int i = tid; i < SS; i += NT) Pk[SS + i] = -sQk[i];  // Pinv[0].main = -Q_0   :75-81
+        if (first) for (int i = tid; i < SS; i += NT) { Pk[SS + i] = -sQk[i]; imP(0, 1, i % S, i / S, -sQk[i]); }  // Pinv[0].main = -Q_0   :75-81
         if (k == 1) for (int i = tid; i < SS; i += NT) sTh0[i] = -sQm[i];    // ... which is this knot's left neighbour
         __syncthreads();
         // ---- 2. six inversions side by side, in place ----
@@ -632,6 +639,8 @@ __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStr
                 Sk[SS + i] = -sQk[i];                                        // :120-126
                 Pk[i] = (T)0;
                 if (last) { Pk[2 * SS + i] = (T)0; Sk[2 * SS + i] = (T)0; }
+                imS(0, 0, i % S, i / S, (T)0); imS(0, 1, i % S, i / S, -sQk[i]); imP(0, 0, i % S, i / S, (T)0);
+                if (last) { imP(0, 2, i % S, i / S, (T)0); imS(0, 2, i % S, i / S, (T)0); }
             }
             __syncthreads();
             for (int i = tid; i < S; i += NT) gamma[i] = c[i] - sv[i];       // :131-146, + c_0 (D4)
@@ -645,6 +654,7 @@ __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStr
                 sPhi1[cc * S + r] = v;
                 Sk[cc * S + r] = -v;                                         // S[k].left = -phi      :388-394
                 Sk[2 * SS - 3 * SS + r * S + cc] = -v;                       // S[k-1].right = -phi^T :443-455
+                imS(k, 0, r, cc, -v); imS(k - 1, 2, cc, r, -v);
             });
         mfma_tiles_on_waves<T, S, C, NW>(wave, lane, TILES,
             [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, C, C, false>(sB1, sRm, mt, nt, lane, acc); },
@@ -671,6 +681,7 @@ __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStr
                 const T th = v + sQk[cc * S + r];
                 sTh1[cc * S + r] = th;
                 Sk[SS + cc * S + r] = -th;                                   // S[k].main   :398-404
+                imS(k, 1, r, cc, -th);
             });
         if (full0)
             mfma_tiles_on_waves<T, S, S, NW>(wave, lane, TILES,
@@ -692,11 +703,12 @@ __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStr
                 for (int i = tid - 2 * WAVE; i < SS; i += NT - 2 * WAVE) {
                     Pk[2 * SS + i] = (T)0;
                     Sk[2 * SS + i] = (T)0;                                   // last right: unused (:166-174)
+                    imP(k, 2, i % S, i / S, (T)0); imS(k, 2, i % S, i / S, (T)0);
                 }
         }
         __syncthreads();
         stamp();                                                             // 3: Schur blocks done
-        for (int i = tid; i < SS; i += NT) Pk[SS + i] = sTh1[i];
+        for (int i = tid; i < SS; i += NT) { Pk[SS + i] = sTh1[i]; imP(k, 1, i % S, i / S, sTh1[i]); }
         // ---- 4. symmetric stair between knots k-1 and k (gato_schur.cuh:497-649; S[k].left = -phi) ----
         mfma_tiles_on_waves<T, S, S, NW>(wave, lane, 0,                      // Pinv[k].main * phi
             [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sTh1, sPhi1, mt, nt, lane, acc); },
@@ -707,10 +719,10 @@ __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStr
         __syncthreads();
         mfma_tiles_on_waves<T, S, S, NW>(wave, lane, 0,                      // Pinv[k].left          :578-611
             [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sT, sTh0, mt, nt, lane, acc); },
-            [&](int r, int cc, T v) { Pk[cc * S + r] = v; });
+            [&](int r, int cc, T v) { Pk[cc * S + r] = v; imP(k, 0, r, cc, v); });
         mfma_tiles_on_waves<T, S, S, NW>(wave, lane, TILES,                  // Pinv[k-1].right       :614-648 (D1)
             [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sT + SS, sTh1, mt, nt, lane, acc); },
-            [&](int r, int cc, T v) { Pk[2 * SS - 3 * SS + cc * S + r] = v; });
+            [&](int r, int cc, T v) { Pk[2 * SS - 3 * SS + cc * S + r] = v; imP(k - 1, 2, r, cc, v); });
         stamp();                                                             // 4: stair written
     }
 }

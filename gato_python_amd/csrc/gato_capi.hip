@@ -146,7 +146,7 @@ struct gato_solver {
     size_t slots_bytes;
     int asm_mode;       // option: 0 = auto, 1 = stage kernels one by one (convert / invert / schur / stair), 2 = fused launch (workgroup per knot), 3 = chunked launch
     int asm_chunk;      // option: knots per workgroup of the chunked launch (0 = auto)
-    int last_asm_fused, stamp_asm;
+    int last_asm_fused, stamp_asm, last_image;
     double *eta_hist;   // eta after init and after every iteration (option record_eta), GATO_ETA_HIST_MAX + 1 entries
     int record_eta;
     // hand-off time-outs: the status word holds the id of the most recent launch that timed out (never cleared by a
@@ -179,6 +179,10 @@ struct gato_solver {
         int mem_kind;                 // 0 uncached, 1 fine-grained, 2 plain hipMalloc
     } cl;
     struct { const void *Ginv, *Cd, *g; void *dz; } fz;   // set by the whole-solve entries: dz may ride in the PCG launch
+    void *imgS, *imgP;                // column-major images of S and Pinv over all rows (one system; nullptr: none), see PcgLaunch::imgS
+    int img_ld;
+    int img_fresh;                    // the fused assembly launch of the whole solve in progress has just written them
+    int no_image;                     // option: the one-workgroup kernels load from S_bd / P_bd as every other kernel
     int dz_fused;                     // the most recent PCG launch also did the dz back-substitution (1: in the solving workgroup, 2: in helper blocks)
     int *dz_flag;                     // device word for the helper blocks of the one-workgroup fp64 launch
     int no_fuse_dz;                   // option
@@ -391,6 +395,15 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     const size_t o_gh = take((size_t)8 * S * e);
     const size_t o_hist = take(sizeof(double) * (GATO_ETA_HIST_MAX + 1));
     const size_t o_xtab = take(sizeof(void *) * GATO_MAX_RANKS);
+    // images for the one-workgroup two-rows-per-lane kernels (one system whose rows fit one of them)
+    const long long rows = (long long)K * S;
+    const bool img = B == 1 && ((s->plan.pair_threads > 0 && rows <= 2ll * s->plan.pair_threads) || (s->plan.mixed_rows > 0 && rows <= s->plan.mixed_rows));
+    int img_ld = 0;
+    if (img) {
+        img_ld = (int)((rows + 63) / 64 * 64) + 128;                    // every lane of the launch reads inside its column
+        if (img_ld < s->plan.mixed_rows) img_ld = s->plan.mixed_rows;
+    }
+    const size_t o_iS = take(img ? (size_t)3 * S * img_ld * e : 0), o_iP = take(img ? (size_t)3 * S * img_ld * e : 0);
     s->arena_bytes = off;
     GATO_HIP_CHECK(hipMalloc((void **)&s->arena, off));
     GATO_HIP_CHECK(hipMemset(s->arena, 0, off));
@@ -409,6 +422,7 @@ extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype,
     s->ghosts = a + o_gh;
     s->eta_hist = (double *)(a + o_hist);
     s->cl_tab = (unsigned long long **)(a + o_xtab);
+    if (img) { s->imgS = a + o_iS; s->imgP = a + o_iP; s->img_ld = img_ld; }
     // placement of the one-XCD launches of the default geometry: measured here, where the caller waits anyway
     // (allocation, memset), never inside an enqueue-only entry.  GATO_NO_TUNE=1 skips it (XCD 0).
     const char *nt = getenv("GATO_NO_TUNE");
@@ -481,6 +495,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "max_workgroups")) s->max_workgroups = value;
     else if (!strcmp(name, "no_fuse_dz")) s->no_fuse_dz = value;
     else if (!strcmp(name, "shared_windows")) s->shared_windows = value;
+    else if (!strcmp(name, "no_image")) s->no_image = value;
     else if (!strcmp(name, "cluster_flat")) s->cluster_flat = value;
     else if (!strcmp(name, "knot_lo") || !strcmp(name, "knot_hi")) {          // stage-level entries: knots [knot_lo, knot_hi)
         if (value < 0 || value > s->d.K) { set_error("%s = %d is outside [0, %d]", name, value, s->d.K); return GATO_EINVAL; }
@@ -541,6 +556,7 @@ extern "C" int gato_solver_get_option(gato_solver *s, const char *name, int *val
     else if (!strcmp(name, "last_variant")) *value = s->last_variant;
     else if (!strcmp(name, "asm_mode")) *value = s->asm_mode;
     else if (!strcmp(name, "last_asm_fused")) *value = s->last_asm_fused;
+    else if (!strcmp(name, "last_image")) *value = s->last_image;
     else if (!strcmp(name, "last_semi")) *value = s->last_semi;
     else if (!strcmp(name, "last_fallback")) *value = s->last_fallback;
     else if (!strcmp(name, "last_dz_fused")) *value = s->dz_fused;
@@ -858,6 +874,10 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.batch = batch;
         a.pair = s->plan_pair;
         a.shared_windows = s->shared_windows;
+        if (s->img_fresh && !s->no_image && batch == 1 && (s->plan_pair == 1 || s->plan_pair == 2) && d_S == s->Sbd && d_Pinv == s->Pbd) {
+            a.imgS = s->imgS; a.imgP = s->imgP; a.img_ld = s->img_ld;
+        }
+        s->last_image = a.imgS != nullptr;
         a.semi = cg1 ? 0 : s->plan_semi;
         a.dpp_rows = cg1 ? 0 : s->plan_dpp;
         // option xcd_pack: -1 = auto (default): up to 32 workgroups are placed on ONE XCD (measured 15-20 % faster hand-offs:
@@ -1077,6 +1097,7 @@ static int assemble(gato_solver *s, int mode, const int *G_row, const int *G_col
     const bool chunked = stair && s->asm_mode == 3;          // measured equal to the stage kernels at best (gato_assembly.hip): opt-in
     const bool fused = chunked || (stair && (s->asm_mode == 2 || (s->asm_mode == 0 && knots <= 2ll * s->num_cus)));
     s->last_asm_fused = chunked ? 2 : fused;
+    s->img_fresh = 0;
     if (!fused) {
         if (mode == 0) {                 // CSR: the gather launch also inverts Q_k, R_k while they sit in LDS
             if (s->d.B > 1 && (s->d.nnzG <= 0 || s->d.nnzC <= 0)) return gato_convert(s, G_row, G_col, G_val, C_row, C_col, C_val, rho, s->G_dense, s->C_dense, st);
@@ -1103,6 +1124,10 @@ static int assemble(gato_solver *s, int mode, const int *G_row, const int *G_col
     a.rho = rho; a.g = d_g; a.c = d_c;
     a.Gd = s->G_dense; a.Cd = const_cast<void *>(C_dense); a.Ginv = s->Ginv; a.Sbd = s->Sbd; a.Pbd = s->Pbd; a.gamma = s->gamma;
     a.stamps = s->stamp_asm ? (unsigned long long *)s->sw.scalars + 8 : nullptr;
+    if (!chunked && s->imgS && !s->no_image && s->d.B == 1) {        // the workgroup-per-knot launch also writes the PCG images
+        a.imgS = s->imgS; a.imgP = s->imgP; a.img_ld = s->img_ld;
+        s->img_fresh = 1;
+    }
     if (chunked) {
         // knots per workgroup: a whole system where there are many (no halo knots at all); else enough chunks for ~2 workgroups
         // per CU, at least 8 knots each (a chunk recomputes two halo knots)
@@ -1135,6 +1160,7 @@ extern "C" int gato_linsys_device(gato_solver *s, const int *d_G_row, const int 
     s->fz = {s->Ginv, s->C_dense, d_g, dz};
     rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream);
     s->fz = {nullptr, nullptr, nullptr, nullptr};
+    s->img_fresh = 0;
     if (rc) return rc;
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[2], (hipStream_t)stream));
     if (!s->dz_fused && (rc = gato_compute_dz(s, s->Ginv, s->C_dense, d_g, lam, dz, stream))) return rc;
@@ -1157,6 +1183,7 @@ extern "C" int gato_linsys_device_blocks(gato_solver *s, const void *d_G_blocks,
     s->fz = {s->Ginv, d_C_blocks, d_g, dz};
     rc = gato_pcg(s, s->Sbd, s->Pbd, s->gamma, lam, exit_tol, max_iters, s->iters, stream);
     s->fz = {nullptr, nullptr, nullptr, nullptr};
+    s->img_fresh = 0;
     if (rc) return rc;
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[2], (hipStream_t)stream));
     if (!s->dz_fused && (rc = gato_compute_dz(s, s->Ginv, d_C_blocks, d_g, lam, dz, stream))) return rc;

@@ -152,6 +152,11 @@ inline BatchStride batch_stride(const Dims &d)
 // ---- persistent (resident) PCG launch description ------------------------------------------
 struct PcgLaunch {
     const void *S_bd, *P_bd, *gamma;
+    // optional (one-workgroup two-rows-per-lane kernels, one system): the same matrices TRANSPOSED - entry (row R = k S + r of
+    // the system, column c of its block row) at img[c * img_ld + R], rows beyond K S and the blocks a first / last block row
+    // lacks are zero - written by assemble_kernel beside S_bd / P_bd, so that a lane's 3S loads are coalesced
+    const void *imgS, *imgP;
+    int img_ld;
     void *lambda;
     const void *lambda0;         // initial guess (true warm start, r0 = gamma - S lambda0) or nullptr = cold start
     int K;
@@ -255,6 +260,8 @@ struct AsmArgs {
     double rho;
     const void *g, *c;
     void *Gd, *Cd, *Ginv, *Sbd, *Pbd, *gamma;
+    void *imgS, *imgP;               // optional (one system): S and Pinv also as column-major images over ALL rows (PcgLaunch::imgS), leading dimension img_ld
+    int img_ld;
     unsigned long long *stamps;      // diagnostic (option stamp_asm): one workgroup's phase boundaries, 100 MHz ticks
     int chunk;                       // > 0: the chunked launch (assemble_chunk_kernel), this many consecutive knots per workgroup
 };

@@ -1156,10 +1156,11 @@ __device__ __forceinline__ void one_system_helper(const PcgLaunch &a, T *scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockDim.x, nwv = nt >> 6, K = a.K;
     if ((blockIdx.x & 7) != 0) return;
     const size_t h = (blockIdx.x >> 3) - 1, nh = (gridDim.x - 1) >> 3;
-    const size_t lines = ((size_t)3 * S * S * K * sizeof(T) + 127) / 128;
+    const size_t bytes = a.imgS ? (size_t)3 * S * a.img_ld * sizeof(T) : (size_t)3 * S * S * K * sizeof(T);   // of each array the solver loads from
+    const size_t lines = (bytes + 127) / 128;
     typedef int I4 __attribute__((ext_vector_type(4)));
-    const I4 *s4 = static_cast<const I4 *>(a.S_bd), *p4 = static_cast<const I4 *>(a.P_bd);
-    const size_t last16 = (size_t)3 * S * S * K * sizeof(T) / 16 - 1;         // last whole 16-byte unit of an array
+    const I4 *s4 = static_cast<const I4 *>(a.imgS ? a.imgS : a.S_bd), *p4 = static_cast<const I4 *>(a.imgS ? a.imgP : a.P_bd);
+    const size_t last16 = bytes / 16 - 1;                                     // last whole 16-byte unit of an array
     I4 acc = {0, 0, 0, 0};
     for (size_t l = h * nt + tid; l < lines; l += nh * nt) {
         const size_t u = l * 8 < last16 ? l * 8 : last16;
@@ -1292,7 +1293,14 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
     float *__restrict__ dL = static_cast<float *>(a.lambda) + sys * S * K;
 
     f32x2 sm[3 * S], pm[3 * S];
-    {
+    if (a.imgS != nullptr) {          // transposed copies written by the assembly launch of this solve (see pcg_single_f64m_kernel)
+        const float *__restrict__ iS = static_cast<const float *>(a.imgS) + 2 * tid, *__restrict__ iP = static_cast<const float *>(a.imgP) + 2 * tid;
+        const size_t ld = (size_t)a.img_ld;            // rows (2 tid, 2 tid + 1) = (j S + r0, j S + r1): the lane's pair
+#pragma unroll
+        for (int c = 0; c < 3 * S; ++c) sm[c] = *reinterpret_cast<const f32x2 *>(iS + c * ld);
+#pragma unroll
+        for (int c = 0; c < 3 * S; ++c) pm[c] = *reinterpret_cast<const f32x2 *>(iP + c * ld);
+    } else {
         const size_t base = (size_t)(active ? j : 0) * 3 * S * S;
 #pragma unroll
         for (int c = 0; c < 3 * S; ++c) sm[c] = *reinterpret_cast<const f32x2 *>(dS + base + c * S + r0);   // even index: 8-byte aligned
@@ -1516,7 +1524,33 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
     {
         const size_t base = (size_t)(active ? j : 0) * 3 * S * S + r0;
         auto ok_col = [&](int c) { return active && !(j == 0 && c < S) && !(j == K - 1 && c >= 2 * S); };   // gato_utils.cuh:157-174
-        if (two) {
+        if (a.imgS != nullptr) {
+            // the assembly launch of this solve also left S and Pinv transposed (column c of ALL rows contiguous, zeros where a
+            // block or a row does not exist): the lane's entries are unit-stride across the wave, no selects
+            const T *__restrict__ iS = static_cast<const T *>(a.imgS) + row0, *__restrict__ iP = static_cast<const T *>(a.imgP) + row0;
+            const size_t ld = (size_t)a.img_ld;
+            if (two) {
+                V2 sv[3 * S];
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) sv[c] = *reinterpret_cast<const V2 *>(iS + c * ld);      // row0 even, ld even: 16-byte aligned
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) { m[c] = sv[c][0]; m[3 * S + c] = sv[c][1]; }
+                constexpr int PB = 14;
+#pragma unroll
+                for (int c0 = 0; c0 < 3 * S; c0 += PB) {
+                    V2 pv[PB];
+#pragma unroll
+                    for (int q = 0; q < PB; ++q) pv[q] = *reinterpret_cast<const V2 *>(iP + (c0 + q) * ld);
+#pragma unroll
+                    for (int q = 0; q < PB; ++q) ptail[c0 + q][tid] = pv[q];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) m[c] = iS[c * ld];
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) m[3 * S + c] = iP[c * ld];
+            }
+        } else if (two) {
             V2 sv[3 * S];
 #pragma unroll
             for (int c = 0; c < 3 * S; ++c) sv[c] = *reinterpret_cast<const V2 *>(dS + base + (size_t)c * S);   // rows r0, r0 + 1: adjacent, 16-byte aligned

@@ -1268,6 +1268,50 @@ def test_dz_by_the_helper_blocks_is_bit_identical_to_the_dz_launch(K, dt):
     check_solve(f"dz by the helper blocks 14/7/{K} {np.dtype(dt).name}", s, S, C, K, dt, tol, 80, res[0][0], res[0][1], f64_tol=1e-9)
 
 
+@pytest.mark.parametrize("K,dt", [(50, np.float64), (37, np.float64), (50, np.float32), (73, np.float32), (9, np.float32), (2, np.float32), (1, np.float32)])
+def test_transposed_images_give_the_bits_of_the_block_rows(K, dt):
+    """Whole solves of one system that a one-workgroup two-rows-per-lane kernel serves: the fused assembly launch also writes S
+    and Pinv transposed (column c of all rows contiguous) and the PCG launch loads its rows from there with unit stride
+    (default); no_image = 1 loads from the block rows as every other kernel does.  Same lambda and dz bit for bit, also through
+    the block-input entry; a stage-level gato_pcg call on the caller's own arrays and a solve in another preconditioner mode
+    never see the images."""
+    from gato_python_amd.solver import Solver
+    S, C = 14, 7
+    s = system(S, C, K, seed=21) if K > 1 else synth.blocks_to_csr(*synth.make_blocks(S, C, 1, 21, False))
+    f64 = dt == np.float64
+    tol = 1e-9 if f64 else 1e-5
+    res = {}
+    for noimg in (0, 1):
+        sol = Solver(S, C, K, dt)
+        sol.set_option("no_image", noimg)
+        dev = sol.upload_system(s)
+        lam, dz = sol.new(S * K), sol.new(sol.N)
+        for rep in range(3):
+            dz.fill_(float("nan"))
+            sol.linsys(*dev, tol, 80, s.rho, lam, dz)
+            sol.check_status()
+        assert sol.get_option("last_image") == (0 if noimg else 1) and sol.get_option("last_pair") == (2 if f64 else 1)
+        res[noimg] = (host(lam).copy(), host(dz).copy())
+        if not noimg:
+            # stage-level PCG on the solver's own S / Pinv / gamma (what the whole solve left there): block rows, not images
+            l2, _ = sol.pcg(sol.buffer_ptr(3), sol.buffer_ptr(4), sol.buffer_ptr(5), tol, 80)
+            assert sol.get_option("last_image") == 0
+            assert np.array_equal(host(l2), res[0][0])
+            if K > 2:
+                sol.set_option("precon_mode", 1)                  # block-Jacobi: stage kernels, no images
+                sol.linsys(*dev, tol, 200, s.rho, lam, dz)
+                sol.check_status()
+                assert sol.get_option("last_image") == 0
+                sol.set_option("precon_mode", 0)
+                sol.linsys(*dev, tol, 80, s.rho, lam, dz)         # and back: images rewritten by this solve's assembly
+                sol.check_status()
+                assert sol.get_option("last_image") == 1
+                assert np.array_equal(host(lam), res[0][0]) and np.array_equal(host(dz), res[0][1])
+        sol.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    check_solve(f"transposed images 14/7/{K} {np.dtype(dt).name}", s, S, C, K, dt, tol, 80, res[0][0], res[0][1], f64_tol=1e-9, two_orders=K <= 2)
+
+
 @pytest.mark.parametrize("K,B,warm", [(50, 1, 0), (73, 1, 0), (49, 1, 1), (19, 1, 0), (10, 1, 1), (9, 1, 0), (2, 1, 0), (1, 1, 0), (50, 5, 0), (23, 7, 0)])
 def test_private_windows_give_the_bits_of_the_shared_windows(K, B, warm):
     """The fp32 two-rows-per-lane kernel (the reference's precision at its own shape: what the drop-in runs at 14/7/50) keeps
