@@ -874,7 +874,9 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.batch = batch;
         a.pair = s->plan_pair;
         a.shared_windows = s->shared_windows;
-        if (s->img_fresh && !s->no_image && batch == 1 && (s->plan_pair == 1 || s->plan_pair == 2) && d_S == s->Sbd && d_Pinv == s->Pbd) {
+        // (every lane of the launch loads rows 2 tid, 2 tid + 1 resp. its own row: all of them must lie inside a column of the image)
+        if (s->img_fresh && !s->no_image && batch == 1 && d_S == s->Sbd && d_Pinv == s->Pbd &&
+            ((s->plan_pair == 1 && 2 * threads <= s->img_ld) || (s->plan_pair == 2 && s->plan.mixed_rows <= s->img_ld))) {
             a.imgS = s->imgS; a.imgP = s->imgP; a.img_ld = s->img_ld;
         }
         s->last_image = a.imgS != nullptr;
