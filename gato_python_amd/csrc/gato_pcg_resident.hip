@@ -1243,6 +1243,15 @@ __device__ __forceinline__ void one_system_helper(const PcgLaunch &a, T *scratch
     }
 }
 
+// Independent accumulation chains per row of the fp32 two-rows-per-lane kernel's products.  One chain of 3S dependent packed
+// FMAs (the reference's left-to-right order, GATO_PAIR_CHAINS = 1) is latency: a SIMD that hosts one wave of the launch idles
+// between them and the compiler pads every one with a wait state.  2 = even columns + odd columns (the order of
+// row_times_window's packed form, which every other fp32 kernel of the family runs): 14/7/50 f32 1.365 -> 1.256 us per
+// iteration (same box; 3 chains 1.27, 4 chains 1.29; S even: a column's parity is its parity inside the 16-byte read).  fp32 parity is measured against the fp64 oracle beside the reference
+// order's own error (tests/f32_parity.py); fp64 keeps the reference's order everywhere.
+#ifndef GATO_PAIR_CHAINS
+#define GATO_PAIR_CHAINS 2
+#endif
 // ---- fp32, one workgroup (or one workgroup per system of a batch), TWO rows per lane --------------------------
 // The single-workgroup loop is instruction-issue bound: with two rows of the same knot per lane
 // the operand-window reads are shared by both rows, the FMAs pair up as v_pk_fma_f32 and the wave count halves
@@ -1339,6 +1348,26 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
 
     auto times_window = [&](const f32x2 (&m)[3 * S], const float *xw) -> f32x2 {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
+#if GATO_PAIR_CHAINS == 2
+        // even and odd columns in chains of their own.  (Written exactly like this: with the accumulators in an array indexed by
+        // column % 2 the scheduler ran one whole chain after the other - no gain - and pinning the interleaved order with empty
+        // asm statements cost as many wait states as it saved; this form compiles to alternating FMAs without any.)
+        f32x2 acc = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+#pragma unroll
+            for (int i = 0; i < SP / 4; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xw + b * SP + i * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i * 4 + e < S) {
+                        if (e & 1) acc1 = __builtin_elementwise_fma(m[b * S + i * 4 + e], f32x2{v[e], v[e]}, acc1);
+                        else acc = __builtin_elementwise_fma(m[b * S + i * 4 + e], f32x2{v[e], v[e]}, acc);
+                    }
+            }
+        }
+        return acc + acc1;
+#else
         f32x2 acc = {0.f, 0.f};
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
@@ -1351,6 +1380,7 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
             }
         }
         return acc;
+#endif
     };
     unsigned epoch = 0;
     auto block_sum = [&](float prod) -> float {
@@ -1479,6 +1509,7 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
 #ifndef GATO_L2_HELPERS
 #define GATO_L2_HELPERS 8
 #endif
+
 template <int S, int W2, int WT, int ABL = 0>
 __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 {
