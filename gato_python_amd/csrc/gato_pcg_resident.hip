@@ -1252,6 +1252,9 @@ __device__ __forceinline__ void one_system_helper(const PcgLaunch &a, T *scratch
 #ifndef GATO_PAIR_CHAINS
 #define GATO_PAIR_CHAINS 2
 #endif
+#if GATO_PAIR_CHAINS != 1 && GATO_PAIR_CHAINS != 2
+#error "GATO_PAIR_CHAINS: 1 (the reference's left-to-right order) or 2 (even + odd columns)"
+#endif
 // ---- fp32, one workgroup (or one workgroup per system of a batch), TWO rows per lane --------------------------
 // The single-workgroup loop is instruction-issue bound: with two rows of the same knot per lane
 // the operand-window reads are shared by both rows, the FMAs pair up as v_pk_fma_f32 and the wave count halves
