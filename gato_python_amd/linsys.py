@@ -9,6 +9,7 @@ All compute happens in libgato_hip.so; a missing library or GPU raises.
 """
 from __future__ import annotations
 
+import array
 import ctypes as ct
 import os
 
@@ -52,12 +53,24 @@ def _shape_from(C_row, len_g, len_c):
     return S.value, C.value, K.value
 
 
+def _from_list(a, code, dt):
+    """Python list / tuple -> contiguous array.  The reference's callers pass lists (test_pendulum_5.py:9-25); array.array
+    converts them about 1.6 x faster than numpy does (the CSR value and index lists are the bulk of a call's host time), with
+    the same double -> float narrowing.  Anything it refuses (nested lists, non-numbers) goes the numpy way and fails there."""
+    try:
+        return np.frombuffer(array.array(code, a), dt)
+    except (TypeError, OverflowError):
+        return np.ascontiguousarray(np.asarray(a, np.float64), dt) if code != "i" else np.ascontiguousarray(a, np.int32)
+
+
 def linsys_solve(G_row, G_col, G_val, C_row, C_col, C_val, g_val, c_val, input_lambda,
                  testiters, exit_tol, max_iters, warm_start, rho):
     f64 = _state["precision"] == "f64"
     dt = np.float64 if f64 else np.float32
-    i32 = lambda a: np.ascontiguousarray(a, np.int32)
-    fl = lambda a: np.ascontiguousarray(np.asarray(a, np.float64), dt)   # narrowing as std::vector<float> does
+    i32 = lambda a: _from_list(a, "i", np.int32) if isinstance(a, (list, tuple)) else np.ascontiguousarray(a, np.int32)
+    # narrowing as std::vector<float> does
+    fl = lambda a: (_from_list(a, "d" if f64 else "f", dt) if isinstance(a, (list, tuple))
+                    else np.ascontiguousarray(np.asarray(a, np.float64), dt))
     G_row, G_col, C_row, C_col = i32(G_row), i32(G_col), i32(C_row), i32(C_col)
     G_val, C_val, g, c, lam_in = fl(G_val), fl(C_val), fl(g_val), fl(c_val), fl(input_lambda)
     testiters = int(testiters)
