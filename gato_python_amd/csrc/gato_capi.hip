@@ -796,7 +796,7 @@ static int plan_cg1(gato_solver *s, int *groups, int *threads, int *kpw)
 // One-XCD launches (xcd_pack): the hand-off granules live in one place in memory and the eight XCDs are not equally far
 // from it - measured 3.00 (best XCD) to 3.27 us (worst) per iteration at 14/7/512 f32, 3.10 to 3.37 at 14/7/1024, the
 // order depending on where this solver's hand-off area happened to land, stable for the life of the solver
-// (tools/xcd_sel_test.py).  The hosting XCD of a geometry is therefore MEASURED: two rounds of eight short trial launches
+// (tools/xcd_sel_check.py).  The hosting XCD of a geometry is therefore MEASURED: two rounds of eight short trial launches
 // (16 iterations each, the second round timed with HIP events; ~1 ms in all, host-blocking), the fastest XCD is kept.
 // This happens in gato_solver_tune() only - called by gato_solver_create for the geometry the solver's defaults plan,
 // and by the caller again after changing geometry options - on the solver's OWN buffers (work vectors as lambda, a
@@ -887,7 +887,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.dpp_rows = cg1 ? 0 : s->plan_dpp;
         // option xcd_pack: -1 = auto (default): up to 32 workgroups are placed on ONE XCD (measured 15-20 % faster hand-offs:
         // 14/7/512 f32 3.96 -> 3.11 us/iteration); spreading over 2..7 XCDs measured no better than the plain grid, so
-        // auto leaves larger launches alone.  0 = off, 1..7 = force that many XCDs (tools/xcd_pack_test.py).
+        // auto leaves larger launches alone.  0 = off, 1..7 = force that many XCDs (tools/xcd_pack_check.py).
         a.xcd_pack = 0;
         if (s->xcd_pack != 0 && batch == 1 && groups > 1) {
             const int need = (groups + 31) / 32;
