@@ -1512,21 +1512,79 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
 #ifndef GATO_L2_HELPERS
 #define GATO_L2_HELPERS 8
 #endif
+// Round 4.  In-kernel s_memtime stamps of one iteration (tools/f64m_stamps.py, wave by wave) said: products 1020 + 1660 cycles of
+// 4560, the two block sums 620 each, quotient + update + window write 260 / 330 - and that the waves sharing a SIMD with a
+// two-row wave finish their products late while the two one-row waves that share the fourth SIMD are done after 690 / 770
+// cycles = 42 reads x 16: a ds_read_b128 occupies its SIMD's LDS return path for 16 cycles (64 B per clock and SIMD; the 256 B
+// per clock of the LDS array needs all four SIMDs reading).  What a SIMD reads per iteration is therefore the bound of the
+// products: 126 reads on three SIMDs (two-row wave 21 + 63, one-row wave 21 + 21), 84 on the fourth.  Changes:
+//  (1) DR: the one-row waves own 16-lane DPP rows (one knot per row, lanes S..15 idle, row_times_dpp: the operand window comes
+//      from the neighbouring lanes' registers, 2 eight-byte LDS reads per product instead of 21 sixteen-byte ones) and FOUR waves
+//      hold two rows per lane, one per SIMD beside one DPP wave: 81 + 2 reads per SIMD and iteration on all four.  The lanes the
+//      DPP rows leave idle are paid for by LDS: K2MAX knots x S / 2 two-row lanes keep Pinv there, less NPR columns that stay in
+//      registers so that it fits (14/7: 34 knots = 238 lanes x 39 pairs + windows = 160.7 KB of 163.8).  Same per-row summation
+//      order as before (left to right): the same bits.
+//  (2) the Pinv pairs in LDS through base registers + 16-bit immediate offsets (the compiler gave every column beyond the offset
+//      range an address register of its own: 20 VGPRs);
+//  (3) the order of LDS reads and FMAs of the two-row products is PINNED (sched_group_barrier: DEPTH reads first, then reads and
+//      FMAs in the block's own ratio): the compiler's order keeps 3-5 reads in flight;
+//  (4) wave-uniform branches around the two forms of a product (readfirstlane) that start with DIFFERENT empty asm statements:
+//      the compiler had hoisted their common first window read and FMA in front of the branch with s_waitcnt lgkmcnt(0)
+//      between them - one exposed LDS latency per product.
+// Measured and not kept (same box, tools/ab_libs.py): block sums on the matrix core (two v_mfma_f64_16x16x4 with B = ones per
+// wave sum + every lane adding the eight wave totals: 1.94 -> 2.04 us per iteration), the divisor-only half of beta = eta' / eta
+// formed during the Pinv product (1.835 -> 1.833), Pinv pairs read before the barrier in front of the Pinv product.
+#ifndef GATO_F64M_D0
+#define GATO_F64M_D0 6      // reads in flight: two-row lanes, S product (21 reads, 84 FMAs)
+#endif
+#ifndef GATO_F64M_D1
+#define GATO_F64M_D1 6      // one-row lanes of the dense layout, either product (21 reads, 42 FMAs); 0 = the compiler's order
+#endif
+#ifndef GATO_F64M_D2
+#define GATO_F64M_D2 9      // two-row lanes, Pinv product (60 or 63 reads, 84 FMAs)
+#endif
+// scheduling pattern for the straight-line block in front of it: DEPTH LDS reads, then (FA FMAs, RA reads) until the reads are
+// out - FA : RA = the block's FMAs per read, so that the number of reads in flight stays at DEPTH - then the remaining FMAs
+template <int DEPTH, int NREAD, int NFMA, int FA, int RA>
+__device__ __forceinline__ void pin_reads_then_fmas()
+{
+    constexpr int D = DEPTH < NREAD ? DEPTH : NREAD, STEPS = (NREAD - D) / RA, TAILR = NREAD - D - STEPS * RA;
+    __builtin_amdgcn_sched_group_barrier(0x100, D, 0);
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x002, FA, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, RA, 0);
+    }
+    if constexpr (TAILR > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x002, FA, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TAILR, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x002, NFMA - FA * (STEPS + (TAILR > 0 ? 1 : 0)), 0);
+}
 
-template <int S, int W2, int WT, int ABL = 0>
+template <int S, int W2, int WT, int ABL = 0, bool DR = false, int K2MAX = 0, int NPR = 0>
 __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 {
     typedef double T;
     typedef double V2 __attribute__((ext_vector_type(2)));
-    constexpr int SP = pad_to(S, 2), NT = 64 * WT, L2 = 64 * W2, ROWS2 = 2 * L2, MAXROWS = ROWS2 + (NT - L2);
-    constexpr int MAXK = (MAXROWS + S - 1) / S;
+    constexpr int SP = pad_to(S, 2), NT = 64 * WT, L2 = 64 * W2;
+    constexpr int KD = DR ? 4 * (WT - W2) : 0;                    // knots of the DPP waves (one per 16-lane row)
+    constexpr int L2U = DR ? K2MAX * (S / 2) : L2;                // two-row lanes that can own rows
+    constexpr int LSTR = DR ? L2U + 1 : L2;                       // lane slots per Pinv column in LDS (DR: + one slot of zeros for the idle lanes)
+    constexpr int NC = 3 * S - NPR;                               // Pinv columns of a two-row lane in LDS (the first NPR in registers)
+    constexpr int MAXK = DR ? K2MAX + KD : (2 * L2 + (NT - L2) + S - 1) / S;
     static_assert(S % 2 == 0 && W2 >= 1 && W2 < WT && WT <= 16, "two adjacent rows of one knot per lane in the first W2 waves");
-    __shared__ __attribute__((aligned(16))) T xs[2][(MAXK + 2) * SP];             // [0] = p window, [1] = r window
+    static_assert(!DR || (DppRows<S>::ok && DppRows<S>::lanes == 16 && L2U <= L2 && L2U < NT && NPR >= 0 && NPR < 3 * S), "DPP rows: one knot per 16 lanes");
+    // ONE operand window: p while the S product reads it, r while the Pinv product does.  Either is written after a barrier
+    // behind the other's last read (the block sum's), so the two never meet - and a second window's 5.8 KB are what lets the
+    // Pinv pairs of 238 two-row lanes fit the LDS with only NPR of them in registers
+    __shared__ __attribute__((aligned(16))) T xs[(MAXK + 2) * SP];
     __shared__ __attribute__((aligned(32))) T wpart[2][4 * WT];
-    __shared__ __attribute__((aligned(16))) V2 ptail[3 * S][L2];                   // Pinv entry c of (row a, row b) of a two-row lane
+    __shared__ __attribute__((aligned(16))) V2 ptail[NC][LSTR];                    // Pinv entry NPR + c of (row a, row b) of a two-row lane
+    static_assert(sizeof(xs) + sizeof(wpart) + sizeof(ptail) <= 160 * 1024, "LDS of one CU");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool two = wave < W2;                                                    // wave-uniform
+    const bool two = __builtin_amdgcn_readfirstlane(wave) < W2;                    // wave-uniform and known as such: scalar branches
     const int K = a.K;
     // One system: the launch brings HELPER blocks (gridDim = 1 + 8 x helpers).  In-kernel time stamps said the solving
     // workgroup spends 15.4 of its 201 us loading its 470 KB of S and Pinv - written a moment ago by the assembly launch on
@@ -1540,9 +1598,28 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         return;
     }
     const size_t sys = a.batch > 1 ? blockIdx.x : 0;
-    const int row0 = two ? 2 * tid : ROWS2 + (tid - L2);
-    const int j = row0 / S, r0 = row0 - j * S;                                     // knot, (first) row inside it
-    const bool active = row0 < K * S;
+    // lane -> row(s).  Dense layout: two-row lanes rows 2 tid, 2 tid + 1, then one row per lane.  DR: the first K - KD knots (at most
+    // K2MAX) in the two-row lanes, the last KD knots one per 16-lane row of the other waves.
+    int row0, j, r0, tp = tid;                                                      // first row, its knot, its row in the knot; lane slot in ptail
+    bool active;
+    if constexpr (DR) {
+        const int K2 = K > KD ? K - KD : 0;
+        if (two) {
+            row0 = 2 * tid; j = row0 / S; r0 = row0 - j * S;
+            active = j < K2;
+            tp = tid < L2U ? tid : L2U;
+        } else {
+            const int q = (tid - L2) >> 4;
+            r0 = tid & 15; j = K2 + q;
+            active = j < K && r0 < S;
+            row0 = j * S + r0;
+            tp = 0;
+        }
+    } else {
+        row0 = two ? 2 * tid : 2 * L2 + (tid - L2);
+        j = row0 / S; r0 = row0 - j * S;
+        active = row0 < K * S;
+    }
     constexpr int abl = ABL;
 
     const T *__restrict__ dS = static_cast<const T *>(a.S_bd) + sys * 3 * S * S * K;
@@ -1550,25 +1627,36 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
     const T *__restrict__ dG = static_cast<const T *>(a.gamma) + sys * S * K;
     T *__restrict__ dL = static_cast<T *>(a.lambda) + sys * S * K;
 
-    // m: two-row lanes [S row a | S row b], one-row lanes [S row | Pinv row]
+    // m: two-row lanes [S row a | S row b], one-row lanes [S row | Pinv row]; pr: the first NPR Pinv pairs of a two-row lane
     // The loads are issued in BATCHES with nothing that needs their data in between: written column by column (load S, load
     // Pinv, select, store the Pinv pair to LDS) the compiler reused one set of registers and waited for every column's loads
     // before the next (84 memory round trips in a row: 9 us of a 198 us launch even with every line in L2).
     T m[6 * S];
+    V2 pr[NPR > 0 ? NPR : 1];
     {
-        const size_t base = (size_t)(active ? j : 0) * 3 * S * S + r0;
+        const bool in_sys = active && j < K;
+        const size_t base = (size_t)(in_sys ? j : 0) * 3 * S * S + (r0 < S ? r0 : 0);
         auto ok_col = [&](int c) { return active && !(j == 0 && c < S) && !(j == K - 1 && c >= 2 * S); };   // gato_utils.cuh:157-174
+        auto keep_pair = [&](int c, V2 v) {                                        // Pinv pair of column c: register or LDS slot
+            if (c < NPR) pr[c < NPR ? c : 0] = v;
+            else ptail[c - NPR][tp] = v;                                           // own slot (idle lanes: zeros, all into the one spare slot)
+        };
         if (a.imgS != nullptr) {
             // the assembly launch of this solve also left S and Pinv transposed (column c of ALL rows contiguous, zeros where a
-            // block or a row does not exist): the lane's entries are unit-stride across the wave, no selects
-            const T *__restrict__ iS = static_cast<const T *>(a.imgS) + row0, *__restrict__ iP = static_cast<const T *>(a.imgP) + row0;
+            // block or a row does not exist): the lane's entries are unit-stride across the wave, no boundary selects (DR: a lane
+            // without rows of its own reads rows of other lanes and drops them)
+            const int rowc = DR ? (active ? row0 : 0) : row0;
+            const T *__restrict__ iS = static_cast<const T *>(a.imgS) + rowc, *__restrict__ iP = static_cast<const T *>(a.imgP) + rowc;
             const size_t ld = (size_t)a.img_ld;
             if (two) {
                 V2 sv[3 * S];
 #pragma unroll
                 for (int c = 0; c < 3 * S; ++c) sv[c] = *reinterpret_cast<const V2 *>(iS + c * ld);      // row0 even, ld even: 16-byte aligned
 #pragma unroll
-                for (int c = 0; c < 3 * S; ++c) { m[c] = sv[c][0]; m[3 * S + c] = sv[c][1]; }
+                for (int c = 0; c < 3 * S; ++c) {
+                    m[c] = (!DR || active) ? sv[c][0] : (T)0;
+                    m[3 * S + c] = (!DR || active) ? sv[c][1] : (T)0;
+                }
                 constexpr int PB = 14;
 #pragma unroll
                 for (int c0 = 0; c0 < 3 * S; c0 += PB) {
@@ -1576,13 +1664,17 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 #pragma unroll
                     for (int q = 0; q < PB; ++q) pv[q] = *reinterpret_cast<const V2 *>(iP + (c0 + q) * ld);
 #pragma unroll
-                    for (int q = 0; q < PB; ++q) ptail[c0 + q][tid] = pv[q];
+                    for (int q = 0; q < PB; ++q) keep_pair(c0 + q, (!DR || active) ? pv[q] : V2{0, 0});
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 3 * S; ++c) m[c] = iS[c * ld];
 #pragma unroll
                 for (int c = 0; c < 3 * S; ++c) m[3 * S + c] = iP[c * ld];
+                if constexpr (DR) {
+#pragma unroll
+                    for (int c = 0; c < 6 * S; ++c) m[c] = active ? m[c] : (T)0;
+                }
             }
         } else if (two) {
             V2 sv[3 * S];
@@ -1602,7 +1694,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 #pragma unroll
                 for (int q = 0; q < PB; ++q) pv[q] = *reinterpret_cast<const V2 *>(dP + base + (size_t)(c0 + q) * S);
 #pragma unroll
-                for (int q = 0; q < PB; ++q) ptail[c0 + q][tid] = ok_col(c0 + q) ? pv[q] : V2{0, 0};      // own lane only: no barrier
+                for (int q = 0; q < PB; ++q) keep_pair(c0 + q, ok_col(c0 + q) ? pv[q] : V2{0, 0});
             }
         } else {
 #pragma unroll
@@ -1617,13 +1709,28 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
             }
         }
     }
-    for (int i = tid; i < 2 * (MAXK + 2) * SP; i += NT) (&xs[0][0])[i] = (T)0;
+    for (int i = tid; i < (MAXK + 2) * SP; i += NT) xs[i] = (T)0;
+    if (tid < 2 * 4 * WT) (&wpart[0][0])[tid] = (T)0;
     __syncthreads();
 
-    // y = [L M R]_row . window for the lane's row(s); which = 0: S, 1: Pinv
-    auto times_window = [&](int which, const T *xw) -> V2 {
+    // the lane's Pinv pairs in LDS: column NPR + c at ptail[c][tp].  A few LDS base registers, the rest 16-bit immediate offsets.
+    typedef __attribute__((address_space(3))) V2 LV2;
+    constexpr int PCH = 65535 / (LSTR * 16) + 1 < NC ? 65535 / (LSTR * 16) + 1 : NC;     // columns per base register
+    constexpr int NBASE = (NC + PCH - 1) / PCH;
+    static_assert((PCH - 1) * LSTR * 16 < 65536 && NBASE <= 4, "immediate offsets of a base register's columns");
+    LV2 *ptb[NBASE];
+#pragma unroll
+    for (int i = 0; i < NBASE; ++i) {
+        ptb[i] = (LV2 *)&ptail[i * PCH][tp];
+        if (i > 0) asm volatile("" : "+v"(ptb[i]));               // opaque: or the compiler re-derives it from ptb[0] with a 17-bit offset
+    }
+    auto pinv_pair = [&](int c) -> V2 { return c < NPR ? pr[c < NPR ? c : 0] : ptb[(c - NPR) / PCH][((c - NPR) % PCH) * LSTR]; };
+    // y = [L M R]_row . window for the lane's row(s); which = 0: S, 1: Pinv; own: the lane's own entries of the operand (DPP rows)
+    auto times_window = [&](int which, const T *xw, V2 own) -> V2 {
         T ya = (T)0, yb = (T)0;
+        constexpr int NW = 3 * (SP / 2);                                         // window reads of a product
         if (two) {
+            asm volatile("; two rows per lane" ::: "memory");
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
 #pragma unroll
@@ -1637,7 +1744,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
                                 ya = gato::fmaT(m[c], v[e], ya);
                                 yb = gato::fmaT(m[3 * S + c], v[e], yb);
                             } else {
-                                const V2 t = ptail[c][tid];
+                                const V2 t = pinv_pair(c);
                                 ya = gato::fmaT(t[0], v[e], ya);
                                 yb = gato::fmaT(t[1], v[e], yb);
                             }
@@ -1645,7 +1752,15 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
                     }
                 }
             }
+            if (which == 0) pin_reads_then_fmas<GATO_F64M_D0, NW, 6 * S, 4, 1>();
+            else pin_reads_then_fmas<GATO_F64M_D2, NW + NC, 6 * S, 4, 3>();
+        } else if constexpr (DR) {
+            asm volatile("; one row per lane, DPP rows" ::: "memory");
+            const int rc = r0 < S ? r0 : S - 1;                                  // idle lanes read inside the window (their rows are zero)
+            const T x3[3] = {xw[rc], own[0], xw[2 * SP + rc]};                   // the lane's row index in knots j - 1, j, j + 1
+            ya = row_times_dpp<T, S>(*reinterpret_cast<const T(*)[3 * S]>(m + (which ? 3 * S : 0)), x3);
         } else {
+            asm volatile("; one row per lane" ::: "memory");
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
 #pragma unroll
@@ -1656,16 +1771,30 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
                         if (i * 2 + e < S) ya = gato::fmaT(m[(which ? 3 * S : 0) + b * S + i * 2 + e], v[e], ya);
                 }
             }
+            if constexpr (GATO_F64M_D1 > 0) pin_reads_then_fmas<GATO_F64M_D1, NW, 3 * S, 2, 1>();
         }
         return V2{ya, yb};
     };
     unsigned epoch = 0;
-    auto block_sum = [&](T prod) -> T {
+#ifdef GATO_F64M_STAMP      // scratch builds only (tools/f64m_stamps.py): s_memtime at the phase boundaries of ONE iteration, per wave
+    unsigned long long st_[16] = {};
+    bool st_on = false;
+#define GATO_ST(i) do { if (st_on) st_[i] = clock64(); } while (0)
+#else
+#define GATO_ST(i) do { } while (0)
+#endif
+    auto block_sum = [&](T prod, int si = 0) -> T {
         ++epoch;
         if (abl & 4) return (T)1 + prod * (T)1e-30;
         T *wp = wpart[epoch & 1];
         partials_store(wp, wave, lane, prod);
+#ifdef GATO_F64M_STAMP
+        if (st_on) st_[si] = clock64();
+#endif
         __syncthreads();
+#ifdef GATO_F64M_STAMP
+        if (st_on) st_[si + 1] = clock64();
+#endif
         return partials_total<T, (WT <= 8 ? 8 : 16)>(wp, WT, lane);
     };
     auto put = [&](T *buf, V2 v) {
@@ -1674,7 +1803,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
             else buf[(j + 1) * SP + r0] = v[0];
         }
     };
-    const T *wp_ = &xs[0][j * SP], *wr_ = &xs[1][j * SP];                        // the lane's windows: slot j = left neighbour
+    const T *wp_ = &xs[j * SP], *wr_ = wp_;                                      // the lane's window: slot j = left neighbour
 
     V2 lam = {0, 0}, r = {0, 0};
     if (active) {
@@ -1687,40 +1816,56 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
             lam[0] = dL0[(size_t)j * S + r0];
             if (two) lam[1] = dL0[(size_t)j * S + r0 + 1];
         }
-        put(xs[0], lam);
+        put(xs, lam);
         __syncthreads();
-        r -= times_window(0, wp_);
+        r -= times_window(0, wp_, lam);
         __syncthreads();
     }
-    put(xs[1], r);
+    put(xs, r);
     __syncthreads();
-    V2 rt = times_window(1, wr_);                                                // gato_pcg.cuh:316-335
+    V2 rt = times_window(1, wr_, r);                                             // gato_pcg.cuh:316-335
     T eta = block_sum(r[0] * rt[0] + r[1] * rt[1]), eta_new = (T)0;
     const bool rec = a.eta_hist && tid == 0 && sys == 0;
     if (rec) a.eta_hist[0] = (double)eta;
     V2 p = rt, ups;
-    put(xs[0], p);
+    put(xs, p);
     __syncthreads();
     int iters = a.max_iters;
     const T tol = (T)a.exit_tol;
     for (int it = 0; it < a.max_iters; ++it) {                                   // gato_pcg.cuh:348
-        ups = (abl & 1) ? p * m[0] : times_window(0, wp_);                       // upsilon = S p         (:349-351)
-        const T v = block_sum(p[0] * ups[0] + p[1] * ups[1]);                    // v = p . upsilon       (:353-357)
+#ifdef GATO_F64M_STAMP
+        st_on = it == a.max_iters - 2;
+#endif
+        GATO_ST(0);
+        ups = (abl & 1) ? p * m[0] : times_window(0, wp_, p);                    // upsilon = S p         (:349-351)
+        GATO_ST(1);
+        const T v = block_sum(p[0] * ups[0] + p[1] * ups[1], 2);                 // v = p . upsilon       (:353-357)
+        GATO_ST(4);
         const T alpha = quotient(eta, v);                                        // :364
         lam += alpha * p;                                                        // :373-377
         r -= alpha * ups;
-        put(xs[1], r);
+        put(xs, r);
+        GATO_ST(5);
         if (!(abl & 8)) __syncthreads();
-        rt = (abl & 2) ? r * m[1] : times_window(1, wr_);                        // r~ = Pinv r           (:380-381)
-        eta_new = block_sum(r[0] * rt[0] + r[1] * rt[1]);                        // eta' = r . r~         (:382-394)
+        GATO_ST(6);
+        rt = (abl & 2) ? r * m[1] : times_window(1, wr_, r);                     // r~ = Pinv r           (:380-381)
+        GATO_ST(7);
+        eta_new = block_sum(r[0] * rt[0] + r[1] * rt[1], 8);                     // eta' = r . r~         (:382-394)
+        GATO_ST(10);
         if (rec) a.eta_hist[it + 1] = (double)eta_new;
         if (fabs(eta_new) < tol) { iters = it; break; }                          // :404-411
         const T beta = quotient(eta_new, eta);                                   // :415
         p = rt + beta * p;                                                       // :416-419
-        put(xs[0], p);
+        put(xs, p);
         eta = eta_new;                                                           // :420
+        GATO_ST(11);
         if (!(abl & 8)) __syncthreads();
+        GATO_ST(12);
     }
+#ifdef GATO_F64M_STAMP
+    if (a.eta_hist && lane == 0 && sys == 0)
+        for (int i = 0; i < 13; ++i) a.eta_hist[1024 + wave * 16 + i] = (double)(st_[i] & 0xffffffffffull);
+#endif
     if (active) {                                                                // :433-435
         dL[(size_t)j * S + r0] = lam[0];
         if (two) dL[(size_t)j * S + r0 + 1] = lam[1];
@@ -1740,8 +1885,10 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         const T *__restrict__ gv = static_cast<const T *>(a.dz_g) + sys * Nn;
         T *__restrict__ dzo = static_cast<T *>(a.dz) + sys * Nn;
         const bool last = k == K - 1;
-        __syncthreads();                                                         // every wave has left the loop: the windows are free
-        put(xs[0], lam);                                                         // lambda window
+        __syncthreads();                                                         // every wave has left the loop: the window and the Pinv pairs are free
+        T *xs0 = xs, *xs1 = reinterpret_cast<T *>(&ptail[0][0]);                 // two windows for the back-substitution
+        static_assert(sizeof(xs) <= sizeof(ptail), "second window of the dz epilogue");
+        put(xs0, lam);                                                           // lambda window
         __syncthreads();
         T tx[2] = {0, 0}, tu[2] = {0, 0};
         if (active) {
@@ -1749,7 +1896,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
                 const int rr = r0 + q;
                 if (!last) {
                     const T *__restrict__ A = Cdn + (size_t)k * cs;
-                    const T *lp = &xs[0][(j + 2) * SP];                          // lambda_{k+1}
+                    const T *lp = &xs0[(j + 2) * SP];                          // lambda_{k+1}
                     T res = (T)0;
 #pragma unroll
                     for (int t = 0; t < S; ++t) res = gato::fmaT(A[rr * S + t], lp[t], res);          // A_k^T lambda_{k+1}   :833-838
@@ -1762,18 +1909,18 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
                         tu[q] = gv[(size_t)k * n + S + rr] - rb;                                      // :792-796
                     }
                 } else tx[q] = gv[(size_t)k * n + rr] - lam[q];                                       // last state row (D2)
-                xs[1][(j + 1) * SP + rr] = tx[q];
+                xs1[(j + 1) * SP + rr] = tx[q];
             }
         }
         __syncthreads();                                                         // lambda_{k+1} has been read everywhere
         if (active && !last) {
             for (int q = 0; q < nrow; ++q)
-                if (r0 + q < Cn) xs[0][(j + 1) * SP + r0 + q] = tu[q];
+                if (r0 + q < Cn) xs0[(j + 1) * SP + r0 + q] = tu[q];
         }
         __syncthreads();
         if (active) {
             const T *__restrict__ Qi = Gi + (size_t)k * gs;
-            const T *tv = &xs[1][(j + 1) * SP];
+            const T *tv = &xs1[(j + 1) * SP];
             for (int q = 0; q < nrow; ++q) {
                 const int rr = r0 + q;
                 T res = (T)0;
@@ -1782,7 +1929,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
                 dzo[(size_t)k * n + rr] = res;
                 if (!last && rr < Cn) {
                     const T *__restrict__ Ri = Qi + S * S;
-                    const T *uv = &xs[0][(j + 1) * SP];
+                    const T *uv = &xs0[(j + 1) * SP];
                     T ru = (T)0;
                     for (int cc = 0; cc < Cn; ++cc) ru = gato::fmaT(Ri[rr + cc * Cn], uv[cc], ru);    // R_k^-1 (...)         :799-808
                     dzo[(size_t)k * n + S + rr] = ru;
@@ -1797,9 +1944,17 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 }
 
 // shape of the mixed kernel per STATE_SIZE (0 = none): waves with two rows per lane, waves in all
-template <int S> struct MixedCfg { static constexpr int w2 = 0, wt = 0; };
-template <> struct MixedCfg<14> { static constexpr int w2 = 3, wt = 8; };      // 3 x 128 + 5 x 64 = 704 rows = 50 knots
-template <int S> constexpr int mixed_rows() { return MixedCfg<S>::wt > 0 ? 128 * MixedCfg<S>::w2 + 64 * (MixedCfg<S>::wt - MixedCfg<S>::w2) : 0; }
+// dr: the one-row waves own 16-lane DPP rows; then k2 = knots the two-row lanes can take (LDS), npr = their Pinv columns in registers
+template <int S> struct MixedCfg { static constexpr int w2 = 0, wt = 0, k2 = 0, npr = 0; static constexpr bool dr = false; };
+template <> struct MixedCfg<14> { static constexpr int w2 = 4, wt = 8, k2 = 34, npr = 1; static constexpr bool dr = true; };   // 34 + 4 x 4 = 50 knots
+template <int S> struct MixedCfgDense { static constexpr int w2 = 0, wt = 0; };                                                  // round 2's layout (option mixed_dense)
+template <> struct MixedCfgDense<14> { static constexpr int w2 = 3, wt = 8; };      // 3 x 128 + 5 x 64 = 704 rows = 50 knots
+template <int S> constexpr int mixed_rows()
+{
+    if (MixedCfg<S>::wt <= 0) return 0;
+    if (MixedCfg<S>::dr) return (MixedCfg<S>::k2 + 4 * (MixedCfg<S>::wt - MixedCfg<S>::w2)) * S;
+    return 128 * MixedCfg<S>::w2 + 64 * (MixedCfg<S>::wt - MixedCfg<S>::w2);
+}
 
 template <int S> struct PairThreads { static constexpr int v = (12 * S + 3 * S + 48) <= 256 ? 512 : ((12 * S + 3 * S + 48) <= 512 ? 256 : 0); };
 template <> struct PairThreads<14> { static constexpr int v = 512; };     // measured: 248 VGPRs, no spill at the 256 cap
@@ -1988,7 +2143,9 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
     }
     if constexpr (sizeof(T) == 8 && MixedCfg<S>::wt > 0) {
         if (a.pair == 2) {
-            constexpr int W2 = MixedCfg<S>::w2, WT = MixedCfg<S>::wt;
+            constexpr int W2 = MixedCfg<S>::w2, WT = MixedCfg<S>::wt, K2 = MixedCfg<S>::k2, NPR = MixedCfg<S>::npr;
+            constexpr bool DR = MixedCfg<S>::dr;
+            static_assert(MixedCfgDense<S>::wt == WT, "both layouts: the same launch");
             if (mr || a.groups != 1 || a.threads != 64 * WT || a.K * S > mixed_rows<S>() || a.stamps) {
                 set_error("pcg_resident(mixed): bad launch K=%d threads=%d", a.K, a.threads);
                 return GATO_EINVAL;
@@ -1996,10 +2153,11 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
             if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
             const dim3 grid(a.batch > 1 ? a.batch : 1 + 8 * GATO_L2_HELPERS), block(64 * WT);          // one system: + helper blocks that warm the L2
             const int abl = a.diag == 2 ? a.ablate : 0;
-            if (abl == 3) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 3>), grid, block, 0, st, a);
-            else if (abl == 4) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 4>), grid, block, 0, st, a);
-            else if (abl == 15) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 15>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 0>), grid, block, 0, st, a);
+            if (a.mixed_dense) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, MixedCfgDense<S>::w2, WT, 0>), grid, block, 0, st, a);
+            else if (abl == 3) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 3, DR, K2, NPR>), grid, block, 0, st, a);
+            else if (abl == 4) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 4, DR, K2, NPR>), grid, block, 0, st, a);
+            else if (abl == 15) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 15, DR, K2, NPR>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 0, DR, K2, NPR>), grid, block, 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;
