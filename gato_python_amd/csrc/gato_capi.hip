@@ -871,6 +871,24 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
                       s->num_cus, s->pcg_threads, s->pcg_groups);
             return GATO_EINVAL;
         }
+        // A launch captured into a graph is REPLAYED with the arguments of the capture.  That is fine for a one-workgroup solve
+        // (nothing in it depends on the launch's number), but not for what draws fresh values per launch: the hand-off epochs of
+        // the multi-workgroup launches (on replay the granules already hold them: polls would pass on stale payloads) and the
+        // dz flag of the helper blocks (it would already equal the launch id: dz from an unfinished lambda).  So while the
+        // stream is being captured the helper blocks do not do dz (the dz launch of its own follows), and a launch that needs
+        // epochs is refused - the streaming kernels (pcg_mode = 2) replay correctly.
+        bool capturing = false;
+        {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+            capturing = cap != hipStreamCaptureStatusNone;
+        }
+        if (capturing && !s->tuning && (groups > 1 || s->cl.on)) {
+            set_error("pcg: a persistent launch of %d workgroups cannot be captured into a graph (its hand-off epochs are launch "
+                      "arguments: a replay would read stale granules); capture the streaming kernels (option pcg_mode = 2) "
+                      "or a system that fits one workgroup", groups);
+            return GATO_EINVAL;
+        }
         PcgLaunch a;
         memset(&a, 0, sizeof(a));
         a.S_bd = d_S; a.P_bd = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda;
@@ -928,7 +946,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         // ONE system through a two-rows-per-lane one-workgroup kernel (pcg_single_f64m_kernel = BASELINE configs[1]; pcg_single_f32x2_kernel): its helper blocks - there
         // to warm the L2 - stay and do dz as soon as lambda is published: the dz launch and the gap in front of it (6.5 us of a
         // 215 us step) become ~1 us at the end of the PCG launch.  no_fuse_dz = 1 keeps the launch of its own.
-        else if (s->fz.dz && !s->no_fuse_dz && batch == 1 && groups == 1 && !cg1 && (s->plan_pair == 2 || s->plan_pair == 1) && !s->stamp_pcg && !s->tuning) {
+        else if (s->fz.dz && !s->no_fuse_dz && batch == 1 && groups == 1 && !cg1 && (s->plan_pair == 2 || s->plan_pair == 1) && !s->stamp_pcg && !s->tuning && !capturing) {
             a.dz_Ginv = s->fz.Ginv; a.dz_Cd = s->fz.Cd; a.dz_g = s->fz.g; a.dz = s->fz.dz; a.C = s->d.C;
             a.dz_helpers = 1; a.dz_flag = s->dz_flag;
             s->dz_fused = 2;
@@ -967,13 +985,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
             s->last_xcd_sel = a.xcd_sel;
         }
         if (s->tuning) return GATO_OK;                                       // nothing to measure for this geometry
-        bool capturing = false;
-        if (gated) {                // the gate queries and records events: not inside a stream capture (the graph's own
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;          // dependencies order its launches)
-            if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
-            capturing = cap != hipStreamCaptureStatusNone;
-        }
-        const bool gate = gated && !capturing;
+        const bool gate = gated && !capturing;      // (a captured multi-workgroup launch was refused above; the gate records events)
         if (gate && (rc = gate_before(s->device, s->num_cus, need_cus, st))) return rc;
         rc = cg1 ? s->ops->pcg_cg1(a, st) : a.semi == 3 ? s->ops->pcg_dma(a, st) : s->ops->pcg_resident(a, st);
         if (rc == GATO_OK && gate) rc = gate_after(s->device, need_cus, st);

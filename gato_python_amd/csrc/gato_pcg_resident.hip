@@ -1195,12 +1195,16 @@ __device__ __forceinline__ void one_system_helper(const PcgLaunch &a, T *scratch
         }
         gi32 *flag = (gi32 *)a.dz_flag;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        // the solve itself may legitimately take longer than the hand-off time-out (max_iters is the caller's): the helpers allow
+        // it 50 us per iteration on top (25 x what an iteration takes) before they call the solving workgroup dead
+        const unsigned long long patience = a.timeout_ticks + (unsigned long long)(a.max_iters > 0 ? a.max_iters : 0) * 5000ull;
         bool late = false;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.launch_id) {
             __builtin_amdgcn_s_sleep(4);                      // ~0.1 us between looks: 50 waves, one load each
-            if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { late = true; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > patience) { late = true; break; }
         }
-        if (late) {         // cannot happen unless the solving workgroup died: report it like a hand-off time-out
+        if (late) {         // cannot happen unless the solving workgroup died: report it like a hand-off time-out (the solving
+            // workgroup, should it still arrive, reads the status word and marks the solve incomplete: iters = -1)
             if (lane == 0) __hip_atomic_store((gi32 *)a.status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
@@ -1492,7 +1496,10 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         if (tid == 0) __hip_atomic_store((gi32 *)a.dz_flag, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) {
-        a.iters[sys] = iters;
+        // a helper block that gave up on this launch (see one_system_helper) left dz rows unwritten: in-band, as a hand-off time-out
+        const bool dz_lost = a.dz_helpers && a.dz != nullptr && a.batch <= 1 &&
+                             __hip_atomic_load((gi32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
+        a.iters[sys] = dz_lost ? -1 : iters;
         if (a.final_eta && sys == 0) *a.final_eta = (double)eta_new;
     }
 }
@@ -1535,13 +1542,13 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
 // wave sum + every lane adding the eight wave totals: 1.94 -> 2.04 us per iteration), the divisor-only half of beta = eta' / eta
 // formed during the Pinv product (1.835 -> 1.833), Pinv pairs read before the barrier in front of the Pinv product.
 #ifndef GATO_F64M_D0
-#define GATO_F64M_D0 6      // reads in flight: two-row lanes, S product (21 reads, 84 FMAs)
+#define GATO_F64M_D0 8      // reads in flight: two-row lanes, S product (21 reads, 84 FMAs)
 #endif
 #ifndef GATO_F64M_D1
 #define GATO_F64M_D1 6      // one-row lanes of the dense layout, either product (21 reads, 42 FMAs); 0 = the compiler's order
 #endif
 #ifndef GATO_F64M_D2
-#define GATO_F64M_D2 9      // two-row lanes, Pinv product (60 or 63 reads, 84 FMAs)
+#define GATO_F64M_D2 8      // two-row lanes, Pinv product (60 or 63 reads, 84 FMAs)
 #endif
 // scheduling pattern for the straight-line block in front of it: DEPTH LDS reads, then (FA FMAs, RA reads) until the reads are
 // out - FA : RA = the block's FMAs per read, so that the number of reads in flight stays at DEPTH - then the remaining FMAs
@@ -1571,7 +1578,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
     constexpr int KD = DR ? 4 * (WT - W2) : 0;                    // knots of the DPP waves (one per 16-lane row)
     constexpr int L2U = DR ? K2MAX * (S / 2) : L2;                // two-row lanes that can own rows
     constexpr int LSTR = DR ? L2U + 1 : L2;                       // lane slots per Pinv column in LDS (DR: + one slot of zeros for the idle lanes)
-    constexpr int NC = 3 * S - NPR;                               // Pinv columns of a two-row lane in LDS (the first NPR in registers)
+    constexpr int NC = 3 * S - NPR;                               // column pairs of a two-row lane in LDS (the other 3S + NPR in registers)
     constexpr int MAXK = DR ? K2MAX + KD : (2 * L2 + (NT - L2) + S - 1) / S;
     static_assert(S % 2 == 0 && W2 >= 1 && W2 < WT && WT <= 16, "two adjacent rows of one knot per lane in the first W2 waves");
     static_assert(!DR || (DppRows<S>::ok && DppRows<S>::lanes == 16 && L2U <= L2 && L2U < NT && NPR >= 0 && NPR < 3 * S), "DPP rows: one knot per 16 lanes");
@@ -1631,15 +1638,32 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
     // The loads are issued in BATCHES with nothing that needs their data in between: written column by column (load S, load
     // Pinv, select, store the Pinv pair to LDS) the compiler reused one set of registers and waited for every column's loads
     // before the next (84 memory round trips in a row: 9 us of a 198 us launch even with every line in L2).
-    T m[6 * S];
-    V2 pr[NPR > 0 ? NPR : 1];
+    // Two-row lanes keep 3S + NPR column PAIRS (row a, row b) in registers, the other 3S - NPR in LDS.  Dense layout: all of S
+    // in registers, all of Pinv in LDS.  DR: the EVEN columns of both matrices in registers (and the last NPR odd ones of Pinv),
+    // the odd ones in LDS - either product then reads 3S/2 windows + 3S/2 pairs, one read per two FMAs throughout: the S
+    // product is bound by the vector units beside a DPP wave (LDS reads are free there), the Pinv product was bound by its
+    // 63 reads (stamps: 850 and 1230 cycles).
+    T m[6 * S + 2 * NPR];
+    auto in_reg = [](int which, int c) -> bool {
+        if (!DR) return which == 0;
+        return c % 2 == 0 || (which == 1 && c >= 3 * S - 2 * NPR);
+    };
+    auto reg_idx = [](int which, int c) -> int {             // pair index in m (entries 2 i, 2 i + 1)
+        if (!DR) return c;
+        if (c % 2 == 0) return (which ? 3 * S / 2 : 0) + c / 2;
+        return 3 * S + (c - (3 * S - 2 * NPR)) / 2;
+    };
+    auto lds_idx = [](int which, int c) -> int {             // column slot in ptail
+        if (!DR) return c;
+        return (which ? 3 * S / 2 : 0) + (c - 1) / 2;
+    };
     {
         const bool in_sys = active && j < K;
         const size_t base = (size_t)(in_sys ? j : 0) * 3 * S * S + (r0 < S ? r0 : 0);
         auto ok_col = [&](int c) { return active && !(j == 0 && c < S) && !(j == K - 1 && c >= 2 * S); };   // gato_utils.cuh:157-174
-        auto keep_pair = [&](int c, V2 v) {                                        // Pinv pair of column c: register or LDS slot
-            if (c < NPR) pr[c < NPR ? c : 0] = v;
-            else ptail[c - NPR][tp] = v;                                           // own slot (idle lanes: zeros, all into the one spare slot)
+        auto keep_pair = [&](int which, int c, V2 v) {                             // pair of column c of S (0) / Pinv (1): registers or LDS slot
+            if (in_reg(which, c)) { m[2 * reg_idx(which, c)] = v[0]; m[2 * reg_idx(which, c) + 1] = v[1]; }
+            else ptail[lds_idx(which, c)][tp] = v;                                 // own slot (idle lanes: zeros, all into the one spare slot)
         };
         if (a.imgS != nullptr) {
             // the assembly launch of this solve also left S and Pinv transposed (column c of ALL rows contiguous, zeros where a
@@ -1653,10 +1677,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 #pragma unroll
                 for (int c = 0; c < 3 * S; ++c) sv[c] = *reinterpret_cast<const V2 *>(iS + c * ld);      // row0 even, ld even: 16-byte aligned
 #pragma unroll
-                for (int c = 0; c < 3 * S; ++c) {
-                    m[c] = (!DR || active) ? sv[c][0] : (T)0;
-                    m[3 * S + c] = (!DR || active) ? sv[c][1] : (T)0;
-                }
+                for (int c = 0; c < 3 * S; ++c) keep_pair(0, c, (!DR || active) ? sv[c] : V2{0, 0});
                 constexpr int PB = 14;
 #pragma unroll
                 for (int c0 = 0; c0 < 3 * S; c0 += PB) {
@@ -1664,7 +1685,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 #pragma unroll
                     for (int q = 0; q < PB; ++q) pv[q] = *reinterpret_cast<const V2 *>(iP + (c0 + q) * ld);
 #pragma unroll
-                    for (int q = 0; q < PB; ++q) keep_pair(c0 + q, (!DR || active) ? pv[q] : V2{0, 0});
+                    for (int q = 0; q < PB; ++q) keep_pair(1, c0 + q, (!DR || active) ? pv[q] : V2{0, 0});
                 }
             } else {
 #pragma unroll
@@ -1681,11 +1702,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 #pragma unroll
             for (int c = 0; c < 3 * S; ++c) sv[c] = *reinterpret_cast<const V2 *>(dS + base + (size_t)c * S);   // rows r0, r0 + 1: adjacent, 16-byte aligned
 #pragma unroll
-            for (int c = 0; c < 3 * S; ++c) {
-                const bool ok = ok_col(c);
-                m[c] = ok ? sv[c][0] : (T)0;
-                m[3 * S + c] = ok ? sv[c][1] : (T)0;
-            }
+            for (int c = 0; c < 3 * S; ++c) keep_pair(0, c, ok_col(c) ? sv[c] : V2{0, 0});
             constexpr int PB = 14;                                                            // Pinv pairs per batch (56 registers)
             static_assert((3 * S) % PB == 0, "batches of Pinv columns");
 #pragma unroll
@@ -1694,7 +1711,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 #pragma unroll
                 for (int q = 0; q < PB; ++q) pv[q] = *reinterpret_cast<const V2 *>(dP + base + (size_t)(c0 + q) * S);
 #pragma unroll
-                for (int q = 0; q < PB; ++q) keep_pair(c0 + q, ok_col(c0 + q) ? pv[q] : V2{0, 0});
+                for (int q = 0; q < PB; ++q) keep_pair(1, c0 + q, ok_col(c0 + q) ? pv[q] : V2{0, 0});
             }
         } else {
 #pragma unroll
@@ -1724,7 +1741,10 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         ptb[i] = (LV2 *)&ptail[i * PCH][tp];
         if (i > 0) asm volatile("" : "+v"(ptb[i]));               // opaque: or the compiler re-derives it from ptb[0] with a 17-bit offset
     }
-    auto pinv_pair = [&](int c) -> V2 { return c < NPR ? pr[c < NPR ? c : 0] : ptb[(c - NPR) / PCH][((c - NPR) % PCH) * LSTR]; };
+    auto pair_of = [&](int which, int c) -> V2 {
+        if (in_reg(which, c)) return V2{m[2 * reg_idx(which, c)], m[2 * reg_idx(which, c) + 1]};
+        return ptb[lds_idx(which, c) / PCH][(lds_idx(which, c) % PCH) * LSTR];
+    };
     // y = [L M R]_row . window for the lane's row(s); which = 0: S, 1: Pinv; own: the lane's own entries of the operand (DPP rows)
     auto times_window = [&](int which, const T *xw, V2 own) -> V2 {
         T ya = (T)0, yb = (T)0;
@@ -1740,20 +1760,20 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
                     for (int e = 0; e < 2; ++e) {
                         const int c = b * S + i * 2 + e;
                         if (i * 2 + e < S) {
-                            if (which == 0) {
-                                ya = gato::fmaT(m[c], v[e], ya);
-                                yb = gato::fmaT(m[3 * S + c], v[e], yb);
-                            } else {
-                                const V2 t = pinv_pair(c);
-                                ya = gato::fmaT(t[0], v[e], ya);
-                                yb = gato::fmaT(t[1], v[e], yb);
-                            }
+                            const V2 t = pair_of(which, c);
+                            ya = gato::fmaT(t[0], v[e], ya);
+                            yb = gato::fmaT(t[1], v[e], yb);
                         }
                     }
                 }
             }
-            if (which == 0) pin_reads_then_fmas<GATO_F64M_D0, NW, 6 * S, 4, 1>();
-            else pin_reads_then_fmas<GATO_F64M_D2, NW + NC, 6 * S, 4, 3>();
+            if constexpr (DR) {
+                if (which == 0) pin_reads_then_fmas<GATO_F64M_D0, NW + 3 * S / 2, 6 * S, 4, 2>();
+                else pin_reads_then_fmas<GATO_F64M_D2, NW + 3 * S / 2 - NPR, 6 * S, 4, 2>();
+            } else {
+                if (which == 0) pin_reads_then_fmas<GATO_F64M_D0, NW, 6 * S, 4, 1>();
+                else pin_reads_then_fmas<GATO_F64M_D2, NW + NC, 6 * S, 4, 3>();
+            }
         } else if constexpr (DR) {
             asm volatile("; one row per lane, DPP rows" ::: "memory");
             const int rc = r0 < S ? r0 : S - 1;                                  // idle lanes read inside the window (their rows are zero)
@@ -1938,7 +1958,10 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         }
     }
     if (tid == 0) {
-        a.iters[sys] = iters;
+        // a helper block that gave up on this launch (see one_system_helper) left dz rows unwritten: in-band, as a hand-off time-out
+        const bool dz_lost = a.dz_helpers && a.dz != nullptr && a.batch <= 1 &&
+                             __hip_atomic_load((gi32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
+        a.iters[sys] = dz_lost ? -1 : iters;
         if (a.final_eta && sys == 0) *a.final_eta = (double)eta_new;
     }
 }
@@ -2151,6 +2174,7 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
                 return GATO_EINVAL;
             }
             if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
+            static_assert(GATO_L2_HELPERS * WT * S >= mixed_rows<S>(), "one helper wave per knot (they do dz)");
             const dim3 grid(a.batch > 1 ? a.batch : 1 + 8 * GATO_L2_HELPERS), block(64 * WT);          // one system: + helper blocks that warm the L2
             const int abl = a.diag == 2 ? a.ablate : 0;
             if (a.mixed_dense) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, MixedCfgDense<S>::w2, WT, 0>), grid, block, 0, st, a);

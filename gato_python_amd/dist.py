@@ -208,6 +208,16 @@ def _all_ranks_ok(ok: bool, group=None) -> bool:
     return bool(int(t.cpu()[0]))
 
 
+def _all_ranks_min(flags, group=None):
+    """Element-wise minimum of a few 0/1 flags over the ranks (one collective; also a barrier)."""
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return [bool(int(v)) for v in t.cpu()]
+
+
 def allreduce_sum_(t, group=None):
     """In-place sum of a device tensor over the ranks (through host memory when the backend is gloo)."""
     import torch.distributed as dist
@@ -258,14 +268,20 @@ class ClusterPCG:
                 err = f"connect: {e}"
         elif not err:
             err = "a peer could not export its mirror"
+        fits = True
         if not err:                   # every rank's knots must fit a persistent launch on its GPU
             g = ct.c_int()
             L.gato_cluster_fits(self.sol._h, ct.byref(g), None)
-            if g.value == 0:
-                err = f"{self.sol.K} knots over {self.nranks} ranks do not fit one persistent launch per GPU"
-        # AND + barrier: every mirror is zeroed and mapped before anyone launches
-        if not _all_ranks_ok(not err, self.group):
+            fits = g.value != 0
+        # AND + barrier: every mirror is zeroed and mapped before anyone launches.  The size verdict travels with it: shards
+        # differ by a knot and GPUs may differ in CUs, so "do not fit" may be true on ONE rank only - and it ends the search over
+        # the memory kinds (first_working_kind), which every rank must leave together or the next collectives mismatch.
+        ok_all, fits_all = _all_ranks_min([not err and fits, fits], self.group)
+        if not ok_all:
             L.gato_cluster_destroy(self.sol._h)
+            if not fits_all:
+                raise ClusterUnavailable(f"{self.sol.K} knots over {self.nranks} ranks do not fit one persistent launch per GPU"
+                                         + ("" if not fits else " (on another rank)"))
             raise ClusterUnavailable(err or "a peer could not map the mirrors")
 
     @staticmethod

@@ -380,6 +380,12 @@ def attach_riders(out, riders):
     cfg["sharded_k4096_us_per_iter"] = k4.get("us_per_iter")
     cfg["same_system_one_gpu_us_per_iter"] = k4.get("one_gpu_us_per_iter")
     cfg["sharded_k4096_speedup_vs_one_gpu"] = k4.get("speedup_vs_one_gpu")
+    # TOP-LEVEL: `value` of this line is N replicas of the K = 50 workload ("scaling": "weak") and reads ~N x
+    # on any node; the STRONG-scaling answer for BASELINE configs[3] - one K = 4096 system sharded over the N GPUs against
+    # the same system on one GPU - stands beside it under a key of its own so that nobody mistakes one for the other
+    # (null when the rider did not deliver; the expectation per N is tabulated in BASELINE.md section 5)
+    out["sharded_speedup"] = k4.get("speedup_vs_one_gpu")
+    out["sharded_speedup_workload"] = "sharded_k4096_f32 (strong scaling: one 14/7/4096 system over the ranks vs the same system on one GPU)"
     return out
 
 

@@ -85,6 +85,34 @@ def main():
     assert outcomes == ["unavailable", "unavailable", "unavailable", "ok"], outcomes
     assert gd._all_ranks_ok(True) is True and gd._all_ranks_ok(rank != 0) is False
 
+    # only rank 1's knots do not fit.  EVERY rank must see the size rejection ("do not fit" ends the search over
+    # the mirror memory kinds): a rank that saw "a peer could not map the mirrors" instead would go on to the next kind and
+    # sit in a collective the others never enter.
+    stub = StubLib(real, False, False, rank != 1)
+    _lib._LIB = stub
+    created = []
+    try:
+        try:
+            gd.ClusterPCG(FakeSolver(), rank, world)
+            raise AssertionError("expected ClusterUnavailable")
+        except gd.ClusterUnavailable as e:
+            assert "do not fit" in str(e), str(e)
+        orig = stub.gato_cluster_create
+
+        def counting_create(*a):
+            created.append(os.environ.get("GATO_XMEM"))
+            return orig(*a)
+        stub.gato_cluster_create = counting_create
+        os.environ.pop("GATO_XMEM", None)
+        try:
+            gd.connect_cluster(FakeSolver(), rank, world, lambda cl: (_ for _ in ()).throw(AssertionError("no probe expected")))
+            raise AssertionError("expected ClusterUnavailable")
+        except gd.ClusterUnavailable as e:
+            assert "do not fit" in str(e), str(e)
+        assert created == ["uncached"], created          # one kind tried, on every rank alike
+    finally:
+        _lib._LIB = real
+
     # connect_cluster: mirrors in each memory kind in turn + a probe solve, every decision an AND over the ranks.
     #  kind "uncached": the probe launch raises on rank 1; "finegrained": rank 0's launch reports a time-out in band
     #  (iters = -1); "plain": every rank's launch completes -> taken, on every rank, with the two rejections recorded

@@ -1382,3 +1382,91 @@ def test_dz_in_the_pcg_epilogue_is_bit_identical_to_the_dz_launch(S, C, K, dt, B
     # (14/7/2 in fp32: a 28-unknown system whose last iterations run on rounding noise - order-chaotic, tools/past_convergence.py)
     check_solve(f"dz in the PCG epilogue {S}/{C}/{K} x{B}", s, S, C, K, dt, tol, 60, res[0][0][:S * K], res[0][1][:n_dz], f64_tol=1e-9,
                 two_orders=K <= 2)
+
+
+def test_mixed_rows_kernel_both_layouts():
+    """Round 4: the one-row waves of pcg_single_f64m_kernel own 16-lane DPP rows (default; four two-row waves beside them, even
+    columns of S and Pinv in registers, odd ones in LDS) - against round 2's dense layout (option mixed_dense) on the same
+    matrices: the per-row products are the same chains, only the grouping of the dot products differs (rounding level), and
+    both stop at the oracle's iteration.  Every K the kernel serves, batches included."""
+    S, C = 14, 7
+    for K in (37, 42, 49, 50):
+        s = synth.make_system(S, C, K, seed=300 + K)
+        Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, np.float64)
+        Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+        Pb = co.form_ss(Sb, Pb, S, K)
+        lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, 1e-10, 300)
+        res = {}
+        for dense in (0, 1):
+            sol = make_solver(S, C, K, np.float64)
+            sol.set_option("mixed_dense", dense)
+            lam, it = sol.pcg(sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam), 1e-10, 300)
+            assert sol.get_option("last_pair") == 2 and int(host(it)[0]) == it_o, (K, dense, int(host(it)[0]), it_o)
+            assert rel(host(lam), lam_o) < 1e-10, (K, dense)
+            res[dense] = host(lam).copy()
+            sol.close()
+        assert rel(res[0], res[1]) < 1e-11, K
+
+
+def test_captured_whole_solve_replays_with_new_inputs():
+    """a whole solve captured into a graph and REPLAYED after the inputs changed in place.  A replay repeats the
+    launch arguments of the capture, so while a stream is being captured the helper blocks of the one-workgroup kernels do not
+    do dz (their flag value would be stale on replay) and a multi-workgroup persistent launch (hand-off epochs) is refused;
+    lambda and dz of every replay must be the oracle's for the inputs of THAT replay."""
+    from gato_python_amd.solver import Solver
+    S, C, K = 14, 7, 50
+    for dt, tol8 in ((np.float64, 1e-9), (np.float32, None)):
+        s1, s2 = system(S, C, K, seed=11), system(S, C, K, seed=12)
+        sol = Solver(S, C, K, dt)
+        dev = list(sol.upload_system(s1))
+        lam, dz = sol.new(S * K), sol.new(sol.N)
+        st = torch.cuda.Stream()
+        tol, mi = (1e-9, 100) if dt == np.float64 else (1e-5, 100)
+        with torch.cuda.stream(st):
+            sol.linsys(*dev, tol, mi, s1.rho, lam, dz)
+            st.synchronize()
+            assert sol.get_option("last_dz_fused") == 2                  # the plain stream: helper blocks do dz
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                sol.linsys(*dev, tol, mi, s1.rho, lam, dz)
+            assert sol.get_option("last_dz_fused") == 0                  # captured: the dz launch of its own
+            for rep, sysm in enumerate((s1, s2, s1, s2, s2)):
+                new = sol.upload_system(sysm)
+                for d, n in zip(dev[2:], new[2:]):                       # values only: the sparsity pattern is the capture's
+                    d.copy_(n)
+                lam.fill_(float("nan")); dz.fill_(float("nan"))
+                g.replay()
+                st.synchronize()
+                sol.check_status()
+                check_solve(f"graph replay {rep} 14/7/{K} {np.dtype(dt).name}", sysm, S, C, K, dt, tol, mi, host(lam), host(dz), f64_tol=1e-9)
+        sol.close()
+    # a launch that needs hand-off epochs cannot be captured: refused with an error, nothing enqueued, capture still valid
+    S, C, K = 14, 7, 512
+    s = system(S, C, K, seed=3)
+    sol = Solver(S, C, K, np.float32)
+    dev = sol.upload_system(s)
+    lam, dz = sol.new(S * K), sol.new(sol.N)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        sol.linsys(*dev, 1e-5, 100, s.rho, lam, dz)
+        st.synchronize()
+        ref = host(lam).copy()
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(_lib.GatoError):
+            with torch.cuda.graph(g, stream=st):
+                sol.linsys(*dev, 1e-5, 100, s.rho, lam, dz)
+    torch.cuda.synchronize()
+    sol.set_option("pcg_mode", 2)                                        # the streaming kernels replay correctly
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        sol.linsys(*dev, 1e-5, 100, s.rho, lam, dz)
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            sol.linsys(*dev, 1e-5, 100, s.rho, lam, dz)
+        for _ in range(3):
+            lam.fill_(float("nan"))
+            g.replay()
+            st.synchronize()
+            assert rel(host(lam), ref) < 1e-4
+    sol.close()

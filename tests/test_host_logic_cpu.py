@@ -180,3 +180,9 @@ def test_bench_multi_gpu_line_carries_the_sharded_results_compactly():
     assert set(cfg["sharded"]) == set(db.DEFAULT_RIDERS)
     assert abs(cfg["sharded"]["sharded_s32_k1024_f32"]["speedup_vs_one_gpu"] - 181.0 / 231.0) < 1e-5
     assert "error" in cfg["sharded"]["sharded_k262144_f32"] and len(line) < 4096
+    # the strong-scaling number of configs[3] is a TOP-LEVEL key of the N > 1 line, beside the replicas `value`
+    assert abs(back["sharded_speedup"] - 181.0 / 231.0) < 1e-5 and "sharded_k4096_f32" in back["sharded_speedup_workload"]
+    assert back["scaling"] == "weak" and back["value"] == 9e5
+    out2 = {"metric": "PCG iterations/s", "value": 9e5, "config": {"workload": "iiwa_14_7_k50_f64"}}
+    db.attach_riders(out2, {"sharded_k4096_f32": {"error": "rider child job did not deliver"}})
+    assert out2["sharded_speedup"] is None                      # a rider that failed leaves the key there, null

@@ -1,5 +1,9 @@
-set -e
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-python tools/ab_libs.py reps=2 build/ab/libgato_drA.so build/ab/libgato_drB.so build/ab/libgato_drC.so > gpurun_out/r4_ab4.log 2>&1
-echo "== dense layout of the same library" >> gpurun_out/r4_ab4.log
-python tools/ab_libs.py reps=1 mixed_dense=1 build/ab/libgato_drA.so >> gpurun_out/r4_ab4.log 2>&1
+timeout -k 10 600 python -m pytest tests -x -q -m gpu > gpurun_out/r4_gputests2.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/r4_gputests2.log
+tail -4 gpurun_out/r4_gputests2.log
+python bench.py > gpurun_out/r4_bench1.jsonl 2> gpurun_out/r4_bench1.err
+tail -c 1200 gpurun_out/r4_bench1.jsonl
+python tools/dropin_latency.py > gpurun_out/r4_dropin0.log 2>&1
+python tools/dropin_latency.py pybind11 >> gpurun_out/r4_dropin0.log 2>&1
+python tools/scaling_inputs.py > gpurun_out/r4_scaling_inputs.log 2>&1
