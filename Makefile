@@ -14,3 +14,4 @@ clean:
 	$(MAKE) -C gato_python_amd/csrc clean
 	$(MAKE) -C oracle clean
 	rm -rf bindings/pybind11/build examples/solve_pendulum
+	$(MAKE) -C bindings/fastseq clean

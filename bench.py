@@ -54,6 +54,8 @@ WORKLOADS = {
     # genuinely HBM-bound: matrices 1.2 GB > 256 MB Infinity Cache
     "iiwa_14_7_k131072_f32": (14, 7, 131072, np.float32, "K far beyond residency (HBM-roofline run)"),
     "s32_c16_k32768_f32": (32, 16, 32768, np.float32, "configs[4]'s shape far beyond residency (S + Pinv 805 MB: HBM-bound)"),
+    # fp64 beyond residency: S + Pinv 617 MB; LDS-DMA ring (pcg_semi = 3), semi-resident (auto), streaming kernels
+    "iiwa_14_7_k65536_f64": (14, 7, 65536, np.float64, "fp64 far beyond residency (S + Pinv 617 MB: HBM-bound)"),
 }
 MAX_ITERS = 100
 PCG_VARIANT = 0     # 1 = opt-in single-reduction (Chronopoulos-Gear) resident kernel, sweep entries only
@@ -487,6 +489,14 @@ def run_sweep(args, torch, emit):
     for mode, semi, tag in ((None, None, ""), (None, 1, "_semi"), (2, None, "_streaming")):
         r, _ = run_single("iiwa_14_7_k131072_f32", 3, 1, torch, pcg_mode=mode, pcg_reps=5, max_iters=20, pcg_semi=semi)
         annotate(r, "iiwa_14_7_k131072_f32" + tag)
+        r["workload"] += tag
+        r["max_iters"] = 20
+        emit(r)
+    # fp64 in the same regime: the ring with 8-byte slots (not auto-selected: within 3 % of the semi-resident
+    # launch), the semi-resident launch (auto) and the streaming kernels
+    for mode, semi, tag in ((None, 3, "_ring"), (None, 1, "_semi"), (2, None, "_streaming")):
+        r, _ = run_single("iiwa_14_7_k65536_f64", 3, 1, torch, pcg_mode=mode, pcg_reps=5, max_iters=20, pcg_semi=semi)
+        annotate(r, "iiwa_14_7_k65536_f64" + tag)
         r["workload"] += tag
         r["max_iters"] = 20
         emit(r)

@@ -184,6 +184,7 @@ struct gato_solver {
     int img_fresh;                    // the fused assembly launch of the whole solve in progress has just written them
     int no_image;                     // option: the one-workgroup kernels load from S_bd / P_bd as every other kernel
     int mixed_dense;                  // option: fp64 mixed-rows kernel in round 2's dense layout (A/B against the DPP-row waves)
+    int coop_launch;                  // option: multi-workgroup persistent launches through hipLaunchCooperativeKernel
     hipEvent_t host_ev[2];            // the host-pointer drop-in's timing events, kept across calls
     int dz_fused;                     // the most recent PCG launch also did the dz back-substitution (1: in the solving workgroup, 2: in helper blocks)
     int *dz_flag;                     // device word for the helper blocks of the one-workgroup fp64 launch
@@ -501,6 +502,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "shared_windows")) s->shared_windows = value;
     else if (!strcmp(name, "no_image")) s->no_image = value;
     else if (!strcmp(name, "mixed_dense")) s->mixed_dense = value;
+    else if (!strcmp(name, "coop_launch")) s->coop_launch = value;
     else if (!strcmp(name, "cluster_flat")) s->cluster_flat = value;
     else if (!strcmp(name, "knot_lo") || !strcmp(name, "knot_hi")) {          // stage-level entries: knots [knot_lo, knot_hi)
         if (value < 0 || value > s->d.K) { set_error("%s = %d is outside [0, %d]", name, value, s->d.K); return GATO_EINVAL; }
@@ -898,6 +900,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.pair = s->plan_pair;
         a.shared_windows = s->shared_windows;
         a.mixed_dense = s->mixed_dense;
+        a.coop = s->coop_launch && groups > 1 && batch == 1 && !cg1;      // (the single-reduction kernel keeps the plain launch)
         // (every lane of the launch loads rows 2 tid, 2 tid + 1 resp. its own row: all of them must lie inside a column of the image)
         if (s->img_fresh && !s->no_image && batch == 1 && d_S == s->Sbd && d_Pinv == s->Pbd &&
             ((s->plan_pair == 1 && 2 * threads <= s->img_ld) || (s->plan_pair == 2 && s->plan.mixed_rows <= s->img_ld))) {

@@ -206,6 +206,7 @@ struct PcgLaunch {
     unsigned long long *stamps;        // optional: diagnostic cycle stamps (16 words), selects the DIAG = 1 build
     int diag;                          // 2: the build with the timing-only switches (ablate) but no stamps
     int mixed_dense;                   // fp64 one-workgroup mixed-rows kernel: round 2's dense one-row waves instead of DPP rows (A/B)
+    int coop;                          // multi-workgroup persistent launches through hipLaunchCooperativeKernel (option coop_launch)
 };
 
 // Cross-GPU mirror of a cluster launch, per epoch parity (granules): one 128-B line per rank for its total (written by

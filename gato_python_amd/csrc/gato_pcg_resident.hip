@@ -2071,6 +2071,18 @@ int launch_plain(const PcgLaunch &a, bool mr, int Kl, hipStream_t st)
             return GATO_OK;
         }
     }
+    // Option coop_launch (A12: cudaLaunchCooperativeKernel + check_sms, gato_pcg.cuh:502-526, gato_utils.cuh:829-854): the
+    // multi-workgroup persistent kernels through hipLaunchCooperativeKernel, so that the RUNTIME keeps the launch from
+    // starting before all its workgroups can be resident (kernels of other streams and processes included), instead of this
+    // library's own gate over its own launches.  Measured cost and verdict: DESIGN.md 3.1b.
+#define GATO_LAUNCH_P(KERNEL, grid_, block_, st_, a_)                                                                          \
+    do {                                                                                                                       \
+        if ((a_).coop) {                                                                                                       \
+            PcgLaunch arg_ = (a_);                                                                                             \
+            void *args_[] = {(void *)&arg_};                                                                                   \
+            (void)hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&KERNEL), grid_, block_, args_, 0, st_);           \
+        } else hipLaunchKernelGGL(KERNEL, grid_, block_, 0, st_, a_);                                                          \
+    } while (0)
     // Hand-off form of the plain and the cluster launches (option wave_pub, default 1): ghost blocks in registers always;
     // per-wave published partials where a sweep - W << ceil(log2(waves)) granules - is at most 4 loads per lane (up to 32
     // workgroups of 8 waves).  wave_pub = 0: the gathered form with the ghost blocks staged in LDS (also what the cycle-stamp
@@ -2085,18 +2097,18 @@ int launch_plain(const PcgLaunch &a, bool mr, int Kl, hipStream_t st)
     auto go = [&](auto mtc) {
         constexpr int MT = decltype(mtc)::value;
         if (mr) {
-            if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, true, 4, DR>), grid, block, 0, st, a);
-            else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, true, -1, DR>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, true, 0, DR>), grid, block, 0, st, a);
+            if (wp) GATO_LAUNCH_P((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, true, 4, DR>), grid, block, st, a);
+            else if (rg) GATO_LAUNCH_P((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, true, -1, DR>), grid, block, st, a);
+            else GATO_LAUNCH_P((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, true, 0, DR>), grid, block, st, a);
         } else if (a.stamps) {
-            if constexpr (!DR) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MAXT0, 0, 1>), grid, block, 0, st, a);
+            if constexpr (!DR) GATO_LAUNCH_P((pcg_resident_kernel<T, S, MAXT0, 0, 1>), grid, block, st, a);
         } else if (a.diag == 2) {
-            if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 2, 0, false, false, 4, DR>), grid, block, 0, st, a);
-            else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 2, 0, false, false, -1, DR>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 2, 0, false, false, 0, DR>), grid, block, 0, st, a);
-        } else if (wp) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, false, 4, DR>), grid, block, 0, st, a);
-        else if (rg) hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, false, -1, DR>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, false, 0, DR>), grid, block, 0, st, a);
+            if (wp) GATO_LAUNCH_P((pcg_resident_kernel<T, S, MT, 0, 2, 0, false, false, 4, DR>), grid, block, st, a);
+            else if (rg) GATO_LAUNCH_P((pcg_resident_kernel<T, S, MT, 0, 2, 0, false, false, -1, DR>), grid, block, st, a);
+            else GATO_LAUNCH_P((pcg_resident_kernel<T, S, MT, 0, 2, 0, false, false, 0, DR>), grid, block, st, a);
+        } else if (wp) GATO_LAUNCH_P((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, false, 4, DR>), grid, block, st, a);
+        else if (rg) GATO_LAUNCH_P((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, false, -1, DR>), grid, block, st, a);
+        else GATO_LAUNCH_P((pcg_resident_kernel<T, S, MT, 0, 0, 0, false, false, 0, DR>), grid, block, st, a);
     };
     constexpr bool HAS512 = MAXT0 > 512 && S >= 12;
     if constexpr (HAS512) {
@@ -2199,8 +2211,8 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
                 return GATO_EINVAL;
             }
             if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-            if (mr) hipLaunchKernelGGL((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v, false, true>), dim3(a.groups), dim3(a.threads), 0, st, a);
-            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v>), dim3(a.groups), dim3(a.threads), 0, st, a);
+            if (mr) GATO_LAUNCH_P((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v, false, true>), dim3(a.groups), dim3(a.threads), st, a);
+            else GATO_LAUNCH_P((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v>), dim3(a.groups), dim3(a.threads), st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;
@@ -2217,8 +2229,8 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
                 return GATO_EINVAL;
             }
             if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-            if (mr) hipLaunchKernelGGL((pcg_resident_kernel<T, S, NT, 0, false, NX, true, true>), dim3(a.groups), dim3(a.threads), 0, st, a);
-            else hipLaunchKernelGGL((pcg_resident_kernel<T, S, NT, 0, false, NX, true>), dim3(a.groups), dim3(a.threads), 0, st, a);
+            if (mr) GATO_LAUNCH_P((pcg_resident_kernel<T, S, NT, 0, false, NX, true, true>), dim3(a.groups), dim3(a.threads), st, a);
+            else GATO_LAUNCH_P((pcg_resident_kernel<T, S, NT, 0, false, NX, true>), dim3(a.groups), dim3(a.threads), st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;

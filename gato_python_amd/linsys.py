@@ -46,17 +46,29 @@ def _shape_from(C_row, len_g, len_c):
     if all(env):
         return tuple(int(v) for v in env)
     S, C, K = ct.c_int(), ct.c_int(), ct.c_int()
-    rc = _lib.lib().gato_infer_shape(C_row.ctypes.data_as(ct.c_void_p), len(C_row), len_g, len_c,
+    rc = _lib.lib().gato_infer_shape(C_row.__array_interface__["data"][0], len(C_row), len_g, len_c,
                                      ct.byref(S), ct.byref(C), ct.byref(K))
     if rc != 0:
         raise ValueError(_lib.lib().gato_last_error().decode())
     return S.value, C.value, K.value
 
 
+try:                                    # bindings/fastseq: the list <-> buffer copies at C speed (built by __graft_entry__.build())
+    from . import _gato_fastseq as _fs
+except ImportError:                     # not built: array.array / numpy below (1.6 x / 4 x slower on lists, same values)
+    _fs = None
+
+
 def _from_list(a, code, dt):
-    """Python list / tuple -> contiguous array.  The reference's callers pass lists (test_pendulum_5.py:9-25); array.array
-    converts them about 1.6 x faster than numpy does (the CSR value and index lists are the bulk of a call's host time), with
-    the same double -> float narrowing.  Anything it refuses (nested lists, non-numbers) goes the numpy way and fails there."""
+    """Python list / tuple -> contiguous array.  The reference's callers pass lists (test_pendulum_5.py:9-25) and the copy of
+    their tens of thousands of Python floats is most of a call's host time: _gato_fastseq.pack (exact-type fast paths in C,
+    include/gato_pyseq.h) where it is built, else array.array (1.6 x faster than numpy), with the same double -> float
+    narrowing.  Anything those refuse (nested lists, non-numbers) goes the numpy way and fails there."""
+    if _fs is not None:
+        try:
+            return np.frombuffer(_fs.pack(a, code), dt)
+        except (TypeError, OverflowError, ValueError):
+            pass
     try:
         return np.frombuffer(array.array(code, a), dt)
     except (TypeError, OverflowError):
@@ -83,7 +95,7 @@ def linsys_solve(G_row, G_col, G_val, C_row, C_col, C_val, g_val, c_val, input_l
     dz = np.empty((S + C) * K - C, dt)
     iters = ct.c_int(-1)
     ms = np.zeros(testiters, np.float32)
-    p = lambda a: a.ctypes.data_as(ct.c_void_p)
+    p = lambda a: a.__array_interface__["data"][0]       # plain address: the argtypes are declared (ctypes.data_as costs 1.5 us each)
     fn = _lib.lib().gato_linsys_solve_f64 if f64 else _lib.lib().gato_linsys_solve_f32
     rc = fn(p(G_row), len(G_row), p(G_col), p(G_val), len(G_val), p(C_row), len(C_row), p(C_col), p(C_val),
             len(C_val), p(g), len(g), p(c), len(c), p(lam_in), S, C, K, testiters, float(exit_tol),
@@ -95,4 +107,7 @@ def linsys_solve(G_row, G_col, G_val, C_row, C_col, C_val, g_val, c_val, input_l
     if os.environ.get("GATO_VERBOSE", "1") != "0":
         print("first run PCG terminated in %d iterations, time:  %f" % (iters.value, ms[0]))   # gpu_library.cu:190
         print("avg time: %f" % (float(ms.sum()) / testiters))                                   # gpu_library.cu:198
+    if _fs is not None:                 # Python floats widened from float32 like the reference's (gpu_library.cu:221-229)
+        k = "d" if f64 else "f"
+        return _fs.unpack(lam, k), _fs.unpack(dz, k)
     return lam.astype(np.float64).tolist(), dz.astype(np.float64).tolist()

@@ -186,3 +186,37 @@ def test_bench_multi_gpu_line_carries_the_sharded_results_compactly():
     out2 = {"metric": "PCG iterations/s", "value": 9e5, "config": {"workload": "iiwa_14_7_k50_f64"}}
     db.attach_riders(out2, {"sharded_k4096_f32": {"error": "rider child job did not deliver"}})
     assert out2["sharded_speedup"] is None                      # a rider that failed leaves the key there, null
+
+
+def test_fast_list_conversion_matches_the_numpy_narrowing():
+    """bindings/fastseq (include/gato_pyseq.h, also what the pybind11 module copies its arguments with): Python lists, tuples
+    and numpy arrays -> float32 / float64 / int32 buffers with the values std::vector<float> / <int> casters would hold
+    (double -> float by rounding, ints where floats are expected), and the outputs back as lists of Python floats."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "bindings", "fastseq"), "-s"])
+    from gato_python_amd import _gato_fastseq as fs
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(5000) * 10.0 ** rng.integers(-30, 30, 5000)).tolist() + [0, -3, 7, True, np.float32(1.25), np.float64(-2.5), np.int64(9)]
+    want = np.asarray([float(v) for v in x], np.float64)
+    assert np.array_equal(np.frombuffer(fs.pack(x, "f"), np.float32), want.astype(np.float32))
+    assert np.array_equal(np.frombuffer(fs.pack(tuple(x), "d"), np.float64), want)
+    for dt in (np.float32, np.float64, np.int32, np.int64, np.uint32):
+        a = (rng.standard_normal(100) * 50).astype(dt)
+        assert np.array_equal(np.frombuffer(fs.pack(a, "f"), np.float32), a.astype(np.float32))
+        assert np.array_equal(np.frombuffer(fs.pack(a[::2], "d"), np.float64), a[::2].astype(np.float64))     # non-contiguous view
+    idx = rng.integers(0, 2 ** 31 - 1, 1000)
+    assert np.array_equal(np.frombuffer(fs.pack(idx.tolist(), "i"), np.int32), idx.astype(np.int32))
+    assert np.array_equal(np.frombuffer(fs.pack(idx.astype(np.int64), "i"), np.int32), idx.astype(np.int32))
+    assert np.array_equal(np.frombuffer(fs.pack(range(7), "i"), np.int32), np.arange(7, dtype=np.int32))
+    assert len(fs.pack([], "f")) == 0
+    for bad, kind, exc in (("abc", "f", TypeError), ([1.5], "i", TypeError), ([2 ** 40], "i", OverflowError), ([[1.0]], "f", TypeError),
+                           (3.0, "f", TypeError), ([None], "d", TypeError), (np.ones(3), "i", TypeError)):
+        with pytest.raises(exc):
+            fs.pack(bad, kind)
+    out = fs.unpack(np.asarray([1.5, -2.25, 3e-40], np.float32), "f")
+    assert out == [float(np.float32(v)) for v in (1.5, -2.25, 3e-40)] and all(type(v) is float for v in out)
+    assert fs.unpack(np.asarray([1e300, -0.0]), "d") == [1e300, -0.0]
+    # and the drop-in's own conversion goes through it
+    from gato_python_amd import linsys
+    assert linsys._fs is fs or linsys._fs is not None
+    assert np.array_equal(linsys._from_list(x, "f", np.float32), want.astype(np.float32))

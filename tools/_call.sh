@@ -1,9 +1,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests -x -q -m gpu > gpurun_out/r4_gputests2.log 2>&1
-echo "pytest rc=$?" >> gpurun_out/r4_gputests2.log
-tail -4 gpurun_out/r4_gputests2.log
-python bench.py > gpurun_out/r4_bench1.jsonl 2> gpurun_out/r4_bench1.err
-tail -c 1200 gpurun_out/r4_bench1.jsonl
-python tools/dropin_latency.py > gpurun_out/r4_dropin0.log 2>&1
-python tools/dropin_latency.py pybind11 >> gpurun_out/r4_dropin0.log 2>&1
-python tools/scaling_inputs.py > gpurun_out/r4_scaling_inputs.log 2>&1
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "foreign_kernel or captured or pybind11 or dropin or pendulum_golden" > gpurun_out/r4_gputests3.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/r4_gputests3.log
+tail -6 gpurun_out/r4_gputests3.log
+python tools/coop_cost.py > gpurun_out/r4_coop_cost.log 2>&1
+python tools/dropin_latency.py > gpurun_out/r4_dropin1.log 2>&1
+python tools/dropin_latency.py pybind11 >> gpurun_out/r4_dropin1.log 2>&1

@@ -58,7 +58,7 @@ if trace:
                 f.write(f'"{k[0]}",{k[1]},{k[2]},{len(g)},{sum(g) / len(g):.0f},{min(g)},{max(g)}\n')
 
 
-DIAG = re.compile(r"pcg_resident_kernel<\w+, \d+, \d+, \d+, (true|1|2),|pcg_single_f64m_kernel<\d+, \d+, \d+, [1-9]\d*>")      # the diagnostic (STAMP) build: bench.py's latency-floor launches
+DIAG = re.compile(r"pcg_resident_kernel<\w+, \d+, \d+, \d+, (true|1|2),|pcg_single_f64m_kernel<\d+, \d+, \d+, [1-9]\d*[,>]")      # the diagnostic (STAMP) build: bench.py's latency-floor launches
 
 
 def counter(kind):
@@ -80,7 +80,8 @@ WL = {"iiwa_14_7_k50_f64": ("pcg_single_f64m_kernel<14", 50), "iiwa_14_7_k50_f32
       "iiwa_14_7_k512_f32": ("pcg_resident_kernel<float, 14", 512), "iiwa_14_7_k4096_f32": ("pcg_resident_kernel<float, 14", 4096),
       "iiwa_14_7_k4096_f64": ("pcg_resident_kernel<double, 14", 4096), "s32_c16_k1024_f32": ("pcg_resident_kernel<float, 32", 1024),
       "iiwa_14_7_k131072_f32": ("pcg_dma_kernel<float, 14", 131072), "iiwa_14_7_k131072_f32_semi": ("pcg_resident_kernel<float, 14", 131072),
-      "s32_c16_k32768_f32": ("pcg_dma_kernel<float, 32", 32768), "s32_c16_k32768_f32_semi": ("pcg_resident_kernel<float, 32", 32768)}
+      "s32_c16_k32768_f32": ("pcg_dma_kernel<float, 32", 32768), "s32_c16_k32768_f32_semi": ("pcg_resident_kernel<float, 32", 32768),
+      "iiwa_14_7_k65536_f64_ring": ("pcg_dma_kernel<double, 14", 65536), "iiwa_14_7_k65536_f64_semi": ("pcg_resident_kernel<double, 14", 65536)}
 bench = one(f"prof_{tag}_bench.json")
 geom = {}
 if bench:
@@ -120,8 +121,8 @@ for name, (prefix, K) in WL.items():
                                       % len(fv))
 # streaming PCG: traffic of one whole gato_pcg call = sum over its launches (init + 2 per iteration).  Two bench
 # entries stream: K = 131072 (20 iterations, 41 launches, the largest grid) and K = 512 (100 iterations, 201 launches)
-def stream_entry(name, pick, launches_per_call, what):
-    keys = [k for k in fetch if k[0].startswith("stream_step_kernel<float, 14") and pick(k[1])]
+def stream_entry(name, pick, launches_per_call, what, ctype="float"):
+    keys = [k for k in fetch if k[0].startswith(f"stream_step_kernel<{ctype}, 14") and pick(k[1])]
     n = sum(len(fetch[k]) for k in keys)
     if not n:
         return
@@ -129,7 +130,7 @@ def stream_entry(name, pick, launches_per_call, what):
     nw = sum(len(write[k]) for k in keys if k in write)
     w_kb = sum(sum(write[k]) for k in keys if k in write)
     traffic[name] = dict(
-        kernel="stream_step_kernel<float, 14, *> (all phases)", launches=n,
+        kernel=f"stream_step_kernel<{ctype}, 14, *> (all phases)", launches=n,
         fetch_size_kb_per_step_launch=f_kb / n, write_size_kb_per_step_launch=w_kb / max(nw, 1),
         hbm_bytes_per_launch=(2 * f_kb / n + w_kb / max(nw, 1)) * 1024 * launches_per_call,
         note="per gato_pcg call of %s = %d stream_step launches; (2 x FETCH_SIZE + WRITE_SIZE) averaged per launch x %d; "
@@ -141,6 +142,9 @@ if grids:
     stream_entry("iiwa_14_7_k131072_f32_streaming", lambda g: g == grids[-1], 41, "20 iterations")
     if len(grids) > 1:
         stream_entry("iiwa_14_7_k512_f32_streaming", lambda g: g == grids[0], 201, "100 iterations")
+gd = sorted({k[1] for k in fetch if k[0].startswith("stream_step_kernel<double, 14")})
+if gd:                                        # fp64 beyond residency (K = 65536, 20 iterations per call)
+    stream_entry("iiwa_14_7_k65536_f64_streaming", lambda g: g == gd[-1], 41, "20 iterations", "double")
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 
 # matrix-core counters of the assembly kernels
