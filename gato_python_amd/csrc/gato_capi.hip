@@ -862,7 +862,8 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
 {
     int groups = 0, threads = 0, kpw = 0;
     int mode = s->pcg_mode;
-    const bool cg1 = s->pcg_variant == 1 && mode != GATO_PCG_STREAMING && !s->true_warm_start &&
+    // pcg_variant: 1 = single-reduction recurrence, 2 = pipelined recurrence (both opt-in, gato_pcg_cg1.hip; same launch geometry)
+    const bool cg1 = (s->pcg_variant == 1 || s->pcg_variant == 2) && mode != GATO_PCG_STREAMING && !s->true_warm_start &&
                      plan_cg1(s, &groups, &threads, &kpw) != 0 && (batch == 1 || groups == 1);
     const bool fits = cg1 || plan_resident(s, &groups, &threads, &kpw) != 0;
     if (cg1) s->plan_pair = 0;
@@ -901,6 +902,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.shared_windows = s->shared_windows;
         a.mixed_dense = s->mixed_dense;
         a.coop = s->coop_launch && groups > 1 && batch == 1 && !cg1;      // (the single-reduction kernel keeps the plain launch)
+        a.pipelined = cg1 && s->pcg_variant == 2;
         // (every lane of the launch loads rows 2 tid, 2 tid + 1 resp. its own row: all of them must lie inside a column of the image)
         if (s->img_fresh && !s->no_image && batch == 1 && d_S == s->Sbd && d_Pinv == s->Pbd &&
             ((s->plan_pair == 1 && 2 * threads <= s->img_ld) || (s->plan_pair == 2 && s->plan.mixed_rows <= s->img_ld))) {
@@ -960,7 +962,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.ev_start = s->time_pcg ? s->ev_pcg0 : nullptr;
         a.ev_stop = s->time_pcg ? s->ev_pcg1 : nullptr;
         s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT;
-        s->last_variant = cg1 ? 1 : 0;
+        s->last_variant = cg1 ? s->pcg_variant : 0;
         s->last_semi = a.semi;
         s->last_stream = st;
         // co-residency: a multi-workgroup launch waits for launches on other streams it would not fit beside

@@ -1506,3 +1506,45 @@ def test_multi_workgroup_solve_beside_a_long_foreign_kernel(K):
         assert np.array_equal(host(lam), ref[0]) and np.array_equal(host(dz), ref[1]), coop
     del B
     sol.close()
+
+
+@pytest.mark.parametrize("S,C,K,dt,opts", [(14, 7, 50, np.float64, {}), (14, 7, 50, np.float32, {}),
+                                           (14, 7, 50, np.float64, dict(pcg_threads=192)),       # 10 knots per workgroup
+                                           (14, 7, 512, np.float64, {}), (14, 7, 512, np.float32, {}),
+                                           (14, 7, 4096, np.float32, {}), (14, 7, 4096, np.float64, {}),
+                                           (32, 16, 300, np.float64, {}), (32, 16, 1024, np.float32, {}),
+                                           (2, 1, 900, np.float64, dict(pcg_threads=64)), (14, 7, 3, np.float64, {})])
+def test_pipelined_variant(S, C, K, dt, opts):
+    """Opt-in pipelined recurrence (pcg_variant = 2, Ghysels-Vanroose: the dots of an iteration travel while its two
+    products run): equals its own numpy restatement (oracle.pcg_pipelined) to rounding and the reference recurrence's
+    solution to solver tolerance, iteration counts within two of each other, bitwise deterministic."""
+    s = synth.make_system(S, C, K, seed=29)
+    Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
+    Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+    Pb = co.form_ss(Sb, Pb, S, K)
+    f64 = dt == np.float64
+    tol = 1e-9 if f64 else 1e-4
+    lam_pp, it_pp = o.pcg_pipelined(Sb, Pb, gam, S, K, tol, 300)
+    lam_ref, it_ref = co.pcg(Sb, Pb, gam, S, K, tol, 300)
+    sol = make_solver(S, C, K, dt)
+    sol.set_option("pcg_variant", 2)
+    for k, v in opts.items():
+        sol.set_option(k, v)
+    dS, dP, dg = sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam)
+    lam, it = sol.pcg(dS, dP, dg, tol, 300)
+    assert sol.get_option("last_variant") == 2
+    assert abs(int(host(it)[0]) - it_pp) <= (1 if f64 else 2), (int(host(it)[0]), it_pp, it_ref)
+    assert abs(int(host(it)[0]) - it_ref) <= 2
+    if f64:
+        assert rel(host(lam), lam_pp) < 1e-7 and rel(host(lam), lam_ref) < 1e-6, (rel(host(lam), lam_pp), rel(host(lam), lam_ref))
+        # a fixed number of iterations: the iterates themselves against the restatement
+        lam12, _ = sol.pcg(dS, dP, dg, 0.0, 12)
+        assert rel(host(lam12), o.pcg_pipelined(Sb, Pb, gam, S, K, 0.0, 12)[0]) < 1e-9
+    else:           # fp32: the converged fp64 solution of the same matrices is the truth for both recurrences
+        conv = co.pcg(Sb.astype(np.float64), Pb.astype(np.float64), gam.astype(np.float64), S, K, 1e-14, 600)[0]
+        check_f32(f"pipelined variant vs its restatement {S}/{C}/{K}", host(lam), lam_pp, conv)
+    lam1, it1 = sol.pcg(dS, dP, dg, tol, 300)
+    lam2, it2 = sol.pcg(dS, dP, dg, tol, 300)
+    assert torch.equal(lam1, lam2) and torch.equal(it1, it2)        # deterministic
+    sol.check_status()
+    sol.close()
