@@ -185,6 +185,7 @@ struct gato_solver {
     int no_image;                     // option: the one-workgroup kernels load from S_bd / P_bd as every other kernel
     int mixed_dense;                  // option: fp64 mixed-rows kernel in round 2's dense layout (A/B against the DPP-row waves)
     int coop_launch;                  // option: multi-workgroup persistent launches through hipLaunchCooperativeKernel
+    int f32_hybrid;                   // option (default 0): fp32 one-workgroup solves of 37..52 knots through the two-row + DPP-row hybrid kernel
     hipEvent_t host_ev[2];            // the host-pointer drop-in's timing events, kept across calls
     int dz_fused;                     // the most recent PCG launch also did the dz back-substitution (1: in the solving workgroup, 2: in helper blocks)
     int *dz_flag;                     // device word for the helper blocks of the one-workgroup fp64 launch
@@ -503,6 +504,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "no_image")) s->no_image = value;
     else if (!strcmp(name, "mixed_dense")) s->mixed_dense = value;
     else if (!strcmp(name, "coop_launch")) s->coop_launch = value;
+    else if (!strcmp(name, "f32_hybrid")) s->f32_hybrid = value;
     else if (!strcmp(name, "cluster_flat")) s->cluster_flat = value;
     else if (!strcmp(name, "knot_lo") || !strcmp(name, "knot_hi")) {          // stage-level entries: knots [knot_lo, knot_hi)
         if (value < 0 || value > s->d.K) { set_error("%s = %d is outside [0, %d]", name, value, s->d.K); return GATO_EINVAL; }
@@ -668,7 +670,7 @@ static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int
         const int L = s->plan.dpp_lanes;
         const bool one_wg_kernel = t == 0 && g <= 1 &&
             ((!s->no_pair && s->plan.pair_threads > 0 && K * (S / 2) <= s->plan.pair_threads) ||
-             (!s->no_pair && !s->no_single_lds && s->plan.mixed_rows > 0 && K * S <= s->plan.mixed_rows && K * S > maxT && !s->cl.on && K == s->d.K) ||
+             (!s->no_pair && !s->no_single_lds && s->plan.mixed_rows > 0 && K * S <= s->plan.mixed_rows && K * L > maxT && !s->cl.on && K == s->d.K) ||
              (K * S > maxT && K * S <= s->plan.single_max_threads && !s->no_single_lds));
         const bool batch_split = s->d.B > 1 && K * L > maxT && K * S <= maxT;          // a batch needs one workgroup per system
         // measured (tools/dpp_ab.py, same box, with the lean hand-off): fp64 14/7/512 2.76 -> 2.56 us per iteration, 14/7/1024
@@ -702,7 +704,10 @@ static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int
         s->plan_pair = 1;
         return 1;
     }
-    if (t == 0 && g <= 1 && !s->no_pair && !s->no_single_lds && s->plan.mixed_rows > 0 && K * S <= s->plan.mixed_rows && K * S > maxT &&
+    // (from the size at which the one-row-per-lane launch no longer fits ONE workgroup: K S > maxT, or - where the DPP-row layout
+    //  would be taken, 16 lanes per knot - K 16 > maxT: 14/7/33..36 fp64 ran as two workgroups at 2.22 us per iteration)
+    const int one_row_lanes = (s->plan.dpp_lanes > 0 && s->dpp_rows != 0 && s->esz == 8) ? s->plan.dpp_lanes : S;
+    if (t == 0 && g <= 1 && !s->no_pair && !s->no_single_lds && s->plan.mixed_rows > 0 && K * S <= s->plan.mixed_rows && K * one_row_lanes > maxT &&
         s->stamp_pcg != 1 && !s->cl.on && K == s->d.K) {
         // fp64 beyond the register-resident single workgroup: one workgroup, two rows per lane in part of the waves
         *groups = 1; *threads = s->plan.mixed_threads; *kpw = K;
@@ -903,6 +908,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.mixed_dense = s->mixed_dense;
         a.coop = s->coop_launch && groups > 1 && batch == 1 && !cg1;      // (the single-reduction kernel keeps the plain launch)
         a.pipelined = cg1 && s->pcg_variant == 2;
+        a.f32_hybrid = s->f32_hybrid;
         // (every lane of the launch loads rows 2 tid, 2 tid + 1 resp. its own row: all of them must lie inside a column of the image)
         if (s->img_fresh && !s->no_image && batch == 1 && d_S == s->Sbd && d_Pinv == s->Pbd &&
             ((s->plan_pair == 1 && 2 * threads <= s->img_ld) || (s->plan_pair == 2 && s->plan.mixed_rows <= s->img_ld))) {

@@ -208,6 +208,7 @@ struct PcgLaunch {
     int mixed_dense;                   // fp64 one-workgroup mixed-rows kernel: round 2's dense one-row waves instead of DPP rows (A/B)
     int coop;                          // multi-workgroup persistent launches through hipLaunchCooperativeKernel (option coop_launch)
     int pipelined;                     // launch_pcg_cg1: the pipelined recurrence (pcg_variant = 2) instead of the single-reduction one
+    int f32_hybrid;                    // fp32 one-workgroup kernel: the hybrid of two-row and DPP-row waves (opt-in: measured equal)
 };
 
 // Cross-GPU mirror of a cluster launch, per epoch parity (granules): one 128-B line per rank for its total (written by

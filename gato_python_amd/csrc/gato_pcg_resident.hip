@@ -1504,6 +1504,292 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
     }
 }
 
+// scheduling pattern for the straight-line block in front of it: DEPTH LDS reads, then (FA FMAs, RA reads) until the reads are
+// out - FA : RA = the block's FMAs per read, so that the number of reads in flight stays at DEPTH - then the remaining FMAs
+template <int DEPTH, int NREAD, int NFMA, int FA, int RA>
+__device__ __forceinline__ void pin_reads_then_fmas()
+{
+    constexpr int D = DEPTH < NREAD ? DEPTH : NREAD, STEPS = (NREAD - D) / RA, TAILR = NREAD - D - STEPS * RA;
+    __builtin_amdgcn_sched_group_barrier(0x100, D, 0);
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x002, FA, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, RA, 0);
+    }
+    if constexpr (TAILR > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x002, FA, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TAILR, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x002, NFMA - FA * (STEPS + (TAILR > 0 ? 1 : 0)), 0);
+}
+
+// ---- fp32, one workgroup, HYBRID: four two-row waves + four DPP-row waves (round 4) ---------------------------------------
+// The kernel above runs 14/7/50 on six waves - two of the four SIMDs host two of them - and its iteration time steps with
+// the number of waves on the busiest SIMD (same box: K = 36, four waves, 1.05 us per iteration; K = 37, five waves, 1.22;
+// K = 50, six, 1.26; K = 73, eight, 1.45): a SIMD's LDS return path (16 cycles per 16-byte read) and its vector issue are
+// what a product costs.  Here every SIMD hosts ONE two-row wave (wave-private operand windows as above, K2 = K - 16 knots,
+// 36 at most) and ONE wave whose lanes own a 16-lane DPP row per knot (16 knots): row_times_dpp takes the operand window of
+// the lane's own knot from the neighbouring lanes' registers, and the entries of the two neighbouring knots are kept BY THE
+// LANE ITSELF - it fetches the neighbours' upsilon (r~) entries from the shared exchange window after the block sum's barrier
+// and applies the owner's own FMA (r - alpha upsilon, r~ + beta p), exactly what the two-row waves do for their halo rows - so
+// these waves read no operand window at all and need no barrier beyond the two of the block sums.  Per-row summation order of
+// both lane kinds = the packed form's (even columns + odd columns): the same per-row bits as the kernel above.
+// MEASURED (same box, tools/tune_pcg.run): 14/7/50 1.234 us per iteration against 1.250 for the six two-row waves, 14/7/37 1.197 /
+// 1.215, 14/7/45 1.232 / 1.220 - no gain worth a default: unlike the fp64 kernel, whose products were bound by what a SIMD pulls
+// through its LDS return path, the fp32 iteration is bound by the serial chain around the two block sums (DPP steps, barrier,
+// quotient, halo FMAs), which EVERY wave of the launch repeats - eight waves repeat it on every SIMD twice.  Opt-in (option
+// f32_hybrid), correct and tested (test_f32_hybrid_kernel_every_size_it_serves); the default stays the kernel above.
+#ifndef GATO_F32H_D
+#define GATO_F32H_D 6       // window reads in flight in a two-row product
+#endif
+template <int S>
+__global__ __launch_bounds__(512) void pcg_single_f32h_kernel(PcgLaunch a)
+{
+    constexpr int H = S / 2, SP = pad_to(S, 4), W2 = 4, WT = 8, NT = 64 * WT, L2 = 64 * W2, KD = 4 * (WT - W2), K2MAX = L2 / H;
+    constexpr int MAXK = K2MAX + KD;
+    static_assert(S % 2 == 0 && DppRows<S>::ok && DppRows<S>::lanes == 16, "two rows per lane / one knot per 16-lane DPP row");
+    __shared__ __attribute__((aligned(16))) float xs[2][(MAXK + 2) * SP];       // exchange windows: [0] upsilon (p, r at set-up), [1] r~
+    __shared__ __attribute__((aligned(16))) float wpart[2][4 * WT];
+    constexpr int PK = (128 - 1 + S - 1) / S + 1 + 2;                 // knots a two-row wave's 128 rows can span + a halo knot on either side
+    static_assert(4 * S - 2 <= 64, "private windows: one halo row per lane");
+    __shared__ __attribute__((aligned(16))) float pwin[2][W2 * PK * SP];        // two-row waves: [0] = p, [1] = r, wave after wave
+    __shared__ __attribute__((aligned(16))) float hscr[WT * (4 * S * S + 6 * S)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool two = __builtin_amdgcn_readfirstlane(wave) < W2;
+    const int K = a.K;
+    if (a.batch <= 1 && blockIdx.x > 0) {
+        one_system_helper<float, S>(a, hscr);
+        return;
+    }
+    const size_t sys = a.batch > 1 ? blockIdx.x : 0;
+    const int K2 = K > KD ? K - KD : 0;
+    int j, r0;                                    // knot, (first) row in it
+    bool active;
+    if (two) { j = tid / H; r0 = 2 * (tid - j * H); active = j < K2; }
+    else { j = K2 + ((tid - L2) >> 4); r0 = tid & 15; active = j < K && r0 < S; }
+    const int rc = r0 < S ? r0 : S - 1;           // idle DPP lanes read inside the windows
+    const int row0 = j * S + r0;
+
+    const float *__restrict__ dS = static_cast<const float *>(a.S_bd) + sys * 3 * S * S * K;
+    const float *__restrict__ dP = static_cast<const float *>(a.P_bd) + sys * 3 * S * S * K;
+    const float *__restrict__ dG = static_cast<const float *>(a.gamma) + sys * S * K;
+    float *__restrict__ dL = static_cast<float *>(a.lambda) + sys * S * K;
+
+    // two-row lanes: pairs (row a, row b) of S (3S) and Pinv (3S); DPP lanes: S row (3S floats), Pinv row (3S floats)
+    float mm[12 * S];
+    {
+        const bool use_img = a.imgS != nullptr;
+        const size_t ld = (size_t)a.img_ld;
+        const int rowc = active ? row0 : 0;
+        const size_t base = (size_t)(active ? j : 0) * 3 * S * S + rc;
+        auto ok_col = [&](int c) { return active && !(j == 0 && c < S) && !(j == K - 1 && c >= 2 * S); };
+        if (two) {
+            f32x2 sv[3 * S], pv[3 * S];
+            if (use_img) {
+                const float *iS = static_cast<const float *>(a.imgS) + rowc, *iP = static_cast<const float *>(a.imgP) + rowc;
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) sv[c] = *reinterpret_cast<const f32x2 *>(iS + c * ld);
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) pv[c] = *reinterpret_cast<const f32x2 *>(iP + c * ld);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) sv[c] = *reinterpret_cast<const f32x2 *>(dS + base + c * S);
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) pv[c] = *reinterpret_cast<const f32x2 *>(dP + base + c * S);
+            }
+#pragma unroll
+            for (int c = 0; c < 3 * S; ++c) {
+                const bool ok = use_img ? active : ok_col(c);
+                mm[2 * c] = ok ? sv[c][0] : 0.f; mm[2 * c + 1] = ok ? sv[c][1] : 0.f;
+                mm[6 * S + 2 * c] = ok ? pv[c][0] : 0.f; mm[6 * S + 2 * c + 1] = ok ? pv[c][1] : 0.f;
+            }
+        } else {
+            if (use_img) {
+                const float *iS = static_cast<const float *>(a.imgS) + rowc, *iP = static_cast<const float *>(a.imgP) + rowc;
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) mm[c] = iS[c * ld];
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) mm[3 * S + c] = iP[c * ld];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) mm[c] = dS[base + (size_t)c * S];
+#pragma unroll
+                for (int c = 0; c < 3 * S; ++c) mm[3 * S + c] = dP[base + (size_t)c * S];
+            }
+#pragma unroll
+            for (int c = 0; c < 3 * S; ++c) {
+                const bool ok = use_img ? active : ok_col(c);
+                mm[c] = ok ? mm[c] : 0.f;
+                mm[3 * S + c] = ok ? mm[3 * S + c] : 0.f;
+            }
+        }
+    }
+    for (int i = tid; i < 2 * (MAXK + 2) * SP; i += NT) (&xs[0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * W2 * PK * SP; i += NT) (&pwin[0][0])[i] = 0.f;
+    __syncthreads();
+    // two-row waves: the wave's rows [R0, R1), its private windows (slot 0 = knot jf - 1) and the lane's halo row
+    int hoff = 0, hpo = 0, own_po = 0, win_po = 0;
+    bool hvalid = false;
+    float *pw_p = &pwin[0][0], *pw_r = &pwin[1][0];
+    if (two) {
+        const int R0 = 128 * wave, R1 = min(R0 + 128, K2 * S);
+        pw_p = &pwin[0][wave * PK * SP]; pw_r = &pwin[1][wave * PK * SP];
+        if (R0 < R1) {
+            const int jf = R0 / S, jl = (R1 - 1) / S, base_row = (jf - 1) * S;
+            const int nb = R0 - base_row, na = (jl + 2) * S - R1;
+            const int hrow = lane < nb ? base_row + lane : R1 + (lane - nb);
+            hvalid = lane < nb + na && hrow >= 0 && hrow < K * S;
+            const int hj = hvalid ? hrow / S : 0, hr = hvalid ? hrow - hj * S : 0;
+            hoff = hvalid ? (hj + 1) * SP + hr : 0;
+            hpo = hvalid ? (hj - jf + 1) * SP + hr : 0;
+            own_po = active ? (j - jf + 1) * SP + r0 : 0;
+            win_po = active ? (j - jf) * SP : 0;
+        }
+    }
+    const int xl_o = j * SP + rc, xr_o = (j + 2) * SP + rc;          // DPP lanes: the lane's row index in knots j - 1 and j + 1 of an exchange window
+
+    // two-row lanes: y = [L M R]_(rows a, b) . window, packed FMAs, even and odd columns in chains of their own (as above)
+    auto times_window = [&](int which, const float *xw) -> f32x2 {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x2 acc = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+#pragma unroll
+            for (int i = 0; i < SP / 4; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xw + b * SP + i * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i * 4 + e < S) {
+                        const int c = (which ? 3 * S : 0) + b * S + i * 4 + e;
+                        const f32x2 mc = {mm[2 * c], mm[2 * c + 1]};
+                        if (e & 1) acc1 = __builtin_elementwise_fma(mc, f32x2{v[e], v[e]}, acc1);
+                        else acc = __builtin_elementwise_fma(mc, f32x2{v[e], v[e]}, acc);
+                    }
+            }
+        }
+        // (the compiler issues all twelve reads up front: 48 landing registers in a kernel whose two-row lanes hold 168 of matrix)
+        pin_reads_then_fmas<GATO_F32H_D, 3 * (SP / 4), 3 * S, 3, 1>();
+        return acc + acc1;
+    };
+    // DPP lanes: the same row product with the window in registers: the neighbours' entries xl, xr and the lane's own x
+    auto times_dpp = [&](int which, float xl, float x, float xr) -> float {
+        const float x3[3] = {xl, x, xr};
+        return row_times_dpp<float, S>(*reinterpret_cast<const float(*)[3 * S]>(mm + (which ? 3 * S : 0)), x3);
+    };
+    unsigned epoch = 0;
+    // block sum; after its barrier the lane fetches from the exchange window `xw` what its halo state needs: hx (two-row lanes:
+    // the entry of their halo row; DPP lanes: the entry of their row index in knot j - 1) and hy (DPP lanes: knot j + 1)
+    auto block_sum_x = [&](float prod, const float *xw, float &hx, float &hy) -> float {
+        ++epoch;
+        float *wp = wpart[epoch & 1];
+        partials_store(wp, wave, lane, prod);
+        __syncthreads();
+        hx = xw[two ? hoff : xl_o];
+        hy = xw[two ? hoff : xr_o];
+        return partials_total<float, 8>(wp, WT, lane);
+    };
+    auto put_x = [&](float *buf, f32x2 v) {                            // own entries into an exchange window
+        if (active) {
+            if (two) *reinterpret_cast<f32x2 *>(buf + (j + 1) * SP + r0) = v;
+            else buf[(j + 1) * SP + r0] = v[0];
+        }
+    };
+    auto put_private = [&](float *pw, f32x2 v, float g) {               // two-row lanes only
+        if (active) *reinterpret_cast<f32x2 *>(pw + own_po) = v;
+        if (hvalid) pw[hpo] = g;
+        wave_lds_fence();
+    };
+    const float *wp_ = pw_p + win_po, *wr_ = pw_r + win_po;
+
+    f32x2 lam = {0.f, 0.f}, r = {0.f, 0.f};
+    if (active) {
+        r[0] = dG[(size_t)j * S + r0];
+        if (two) r[1] = dG[(size_t)j * S + r0 + 1];
+    }
+    // halo state: two-row lanes g0 = their halo row's entry; DPP lanes g0 / g1 = their row's entry in knots j - 1 / j + 1
+    float gr0 = 0.f, gr1 = 0.f, gp0 = 0.f, gp1 = 0.f;
+    if (a.lambda0) {                                                       // true warm start (opt-in): r = gamma - S lambda0
+        const float *__restrict__ dL0 = static_cast<const float *>(a.lambda0) + sys * S * K;
+        if (active) {
+            lam[0] = dL0[(size_t)j * S + r0];
+            if (two) lam[1] = dL0[(size_t)j * S + r0 + 1];
+        }
+        put_x(xs[0], lam);
+        __syncthreads();
+        if (two) r -= times_window(0, &xs[0][j * SP]);
+        else r[0] -= times_dpp(0, xs[0][xl_o], lam[0], xs[0][xr_o]);
+        __syncthreads();
+    }
+    put_x(xs[0], r);
+    __syncthreads();
+    gr0 = two ? (hvalid ? xs[0][hoff] : 0.f) : xs[0][xl_o];
+    gr1 = two ? 0.f : xs[0][xr_o];
+    f32x2 rt = {0.f, 0.f};
+    if (two) {
+        put_private(pw_r, r, gr0);
+        rt = times_window(1, wr_);                                         // gato_pcg.cuh:316-335
+    } else rt[0] = times_dpp(1, gr0, r[0], gr1);
+    put_x(xs[1], rt);
+    float hx = 0.f, hy = 0.f;
+    float eta = block_sum_x(r[0] * rt[0] + r[1] * rt[1], xs[1], hx, hy), eta_new = 0.f;
+    const bool rec = a.eta_hist && tid == 0 && sys == 0;
+    if (rec) a.eta_hist[0] = (double)eta;
+    f32x2 p = rt, ups = {0.f, 0.f};
+    gp0 = hx; gp1 = two ? 0.f : hy;
+    if (two) {
+        if (!hvalid) gp0 = 0.f;
+        put_private(pw_p, p, gp0);
+    }
+    int iters = a.max_iters;
+    const float tol = (float)a.exit_tol;
+    for (int it = 0; it < a.max_iters; ++it) {                             // gato_pcg.cuh:348
+        if (two) ups = times_window(0, wp_);
+        else ups[0] = times_dpp(0, gp0, p[0], gp1);
+        put_x(xs[0], ups);
+        const float v = block_sum_x(p[0] * ups[0] + p[1] * ups[1], xs[0], hx, hy);
+        const float alpha = quotient(eta, v);
+        lam += alpha * p;
+        r -= alpha * ups;
+        gr0 -= alpha * hx;
+        if (two) {
+            asm volatile("" : "+v"(gr0) : : "memory");     // the halo value first: no wait for hx BETWEEN the two LDS writes
+            put_private(pw_r, r, gr0);
+            rt = times_window(1, wr_);
+        } else {
+            gr1 -= alpha * hy;
+            rt[0] = times_dpp(1, gr0, r[0], gr1);
+        }
+        put_x(xs[1], rt);
+        eta_new = block_sum_x(r[0] * rt[0] + r[1] * rt[1], xs[1], hx, hy);
+        if (rec) a.eta_hist[it + 1] = (double)eta_new;
+        if (fabsf(eta_new) < tol) { iters = it; break; }                   // :404-411
+        const float beta = quotient(eta_new, eta);
+        p = rt + beta * p;
+        eta = eta_new;
+        gp0 = hx + beta * gp0;
+        if (two) {
+            asm volatile("" : "+v"(gp0) : : "memory");
+            put_private(pw_p, p, gp0);
+        } else gp1 = hy + beta * gp1;
+    }
+    if (active) {
+        dL[(size_t)j * S + r0] = lam[0];
+        if (two) dL[(size_t)j * S + r0 + 1] = lam[1];
+    }
+    if (a.dz_helpers && a.dz != nullptr && a.batch <= 1) {       // lambda is complete: release it and tell the helper blocks
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store((gi32 *)a.dz_flag, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+        const bool dz_lost = a.dz_helpers && a.dz != nullptr && a.batch <= 1 &&
+                             __hip_atomic_load((gi32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
+        a.iters[sys] = dz_lost ? -1 : iters;
+        if (a.final_eta && sys == 0) *a.final_eta = (double)eta_new;
+    }
+}
+
 // threads of the two-rows-per-lane kernel: 2*3S*2 matrix registers + window + state must stay under the cap
 // ---- fp64, one workgroup, MIXED rows per lane (IIWA 14/7/50 in fp64 = BASELINE configs[1]) -------------------------------
 // The one-workgroup loop is bound by its LDS reads: every lane reads the 3S-entry operand window of its knot for each
@@ -1550,25 +1836,6 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
 #ifndef GATO_F64M_D2
 #define GATO_F64M_D2 8      // two-row lanes, Pinv product (60 or 63 reads, 84 FMAs)
 #endif
-// scheduling pattern for the straight-line block in front of it: DEPTH LDS reads, then (FA FMAs, RA reads) until the reads are
-// out - FA : RA = the block's FMAs per read, so that the number of reads in flight stays at DEPTH - then the remaining FMAs
-template <int DEPTH, int NREAD, int NFMA, int FA, int RA>
-__device__ __forceinline__ void pin_reads_then_fmas()
-{
-    constexpr int D = DEPTH < NREAD ? DEPTH : NREAD, STEPS = (NREAD - D) / RA, TAILR = NREAD - D - STEPS * RA;
-    __builtin_amdgcn_sched_group_barrier(0x100, D, 0);
-#pragma unroll
-    for (int i = 0; i < STEPS; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x002, FA, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, RA, 0);
-    }
-    if constexpr (TAILR > 0) {
-        __builtin_amdgcn_sched_group_barrier(0x002, FA, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, TAILR, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x002, NFMA - FA * (STEPS + (TAILR > 0 ? 1 : 0)), 0);
-}
-
 template <int S, int W2, int WT, int ABL = 0, bool DR = false, int K2MAX = 0, int NPR = 0>
 __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 {
@@ -2169,7 +2436,17 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
             // one system: + helper blocks (enough waves for one knot each: they also do dz), see pcg_single_f64m_kernel
             const int helpers = (a.K + a.threads / 64 - 1) / (a.threads / 64);
             const dim3 grid(a.batch > 1 ? a.batch : 1 + 8 * helpers);
-            if (a.shared_windows) hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT, false>), grid, dim3(a.threads), 0, st, a);
+            // more than four two-row waves, at most 36 + 16 knots (S = 14): the hybrid of two-row and DPP-row waves, always 8 waves
+            bool hybrid = false;
+            if constexpr (DppRows<S>::ok && DppRows<S>::lanes == 16 && PT >= 512) {
+                hybrid = !a.shared_windows && a.f32_hybrid && a.threads > 256 && a.K <= 256 / (S / 2) + 16;
+                if (hybrid) {
+                    const dim3 gridh(a.batch > 1 ? a.batch : 1 + 8 * ((a.K + 7) / 8));
+                    hipLaunchKernelGGL((pcg_single_f32h_kernel<S>), gridh, dim3(512), 0, st, a);
+                }
+            }
+            if (hybrid) { }
+            else if (a.shared_windows) hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT, false>), grid, dim3(a.threads), 0, st, a);
             else hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT, true>), grid, dim3(a.threads), 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));

@@ -171,7 +171,7 @@ class HipShardBackend:
         return v.value != 0
 
 
-def linsys_solve_sharded(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None):
+def linsys_solve_sharded(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None, sol=None):
     """Whole solve with the PCG sharded over the ranks of `group`.  Assembly (CSR scatter, Schur, stair)
     is replicated on every rank from the replicated CSR inputs - it is a one-off O(K) step and replication
     needs no exchange (SURVEY.md section 8e lists the halo terms it would otherwise need) - then the PCG
@@ -182,7 +182,8 @@ def linsys_solve_sharded(sysm, exit_tol, max_iters, dtype=np.float32, device=Non
     from .solver import Solver
     rank, nranks = dist.get_rank(group), dist.get_world_size(group)
     dev = torch.cuda.current_device() if device is None else device
-    sol = Solver(sysm.S, sysm.C, sysm.K, dtype, dev)
+    if sol is None:                 # (pass the solver of an earlier call back in: creating one runs the XCD calibration trials)
+        sol = Solver(sysm.S, sysm.C, sysm.K, dtype, dev)
     d = sol.upload_system(sysm)
     Gd, Cd = sol.convert(*d[:6], sysm.rho)
     Sb, Pb, gam, Gi = sol.form_schur(Gd, Cd, d[6], d[7])
@@ -495,6 +496,8 @@ def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=Non
         except ClusterUnavailable:
             sol.close()
             raise
+    created_here = "transport" not in state and state.get("_fresh", True)
+    state["_fresh"] = False
     sol, d, cl = state["sol"], state["d"], state["cl"]
     b = state["bufs"] = assemble_shard(sol, d, sysm.rho, cl.k0, cl.k1, state.get("bufs"))
     dev = b["Sb"].device
@@ -513,6 +516,12 @@ def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=Non
         except Exception:         # noqa: BLE001
             ok = False
         if not _all_ranks_ok(ok, group):
+            if created_here:        # the caller never saw this state: nobody else can free the mirrors and the arena
+                try:
+                    cl.close()
+                    sol.close()
+                except Exception:     # noqa: BLE001
+                    pass
             raise ClusterTimeout("a hand-off of the cluster solve timed out" + ("" if ok else " on this rank"))
     return lam, dz, iters, state
 
@@ -534,6 +543,7 @@ def linsys_solve_auto(sysm, exit_tol, max_iters, dtype=np.float32, device=None, 
                 except Exception:     # noqa: BLE001
                     pass
             state = dict(transport="rccl", why=str(e)[:300])
-    lam, dz, iters, sol = linsys_solve_sharded(sysm, exit_tol, max_iters, dtype, device, group)
-    sol.close()
+    # the RCCL schedule keeps its solver across calls (state["rccl_sol"]): a new one per call would run the calibration trials again
+    lam, dz, iters, sol = linsys_solve_sharded(sysm, exit_tol, max_iters, dtype, device, group, sol=state.get("rccl_sol"))
+    state["rccl_sol"] = sol
     return lam, dz, iters, state

@@ -562,11 +562,11 @@ def test_dpp_rows_same_bits_as_the_lds_windows_where_the_geometry_is_the_same(S,
 
 
 def test_mixed_rows_kernel_every_size_it_serves():
-    """pcg_single_f64m_kernel (fp64, one workgroup, two rows per lane in three of its eight waves): every K it is
-    selected for at 14/7 - 37 (the first size beyond 512 register-resident rows) to 50 - against the oracle in fp64, with
-    and without a true warm start, and against the one-row-per-lane kernel on the same system."""
+    """pcg_single_f64m_kernel (fp64, one workgroup, two rows per lane in four of its eight waves, DPP rows in the others):
+    every K it is selected for at 14/7 - 33 (the first size whose DPP rows no longer fit one 512-thread workgroup) to 50 -
+    against the oracle in fp64, with and without a true warm start, and against the one-row-per-lane kernels on the same system."""
     S, C = 14, 7
-    for K in range(37, 51):
+    for K in range(33, 51):
         s = synth.make_system(S, C, K, seed=100 + K)
         Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, np.float64)
         Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
@@ -577,7 +577,8 @@ def test_mixed_rows_kernel_every_size_it_serves():
             sol = make_solver(S, C, K, np.float64)
             sol.set_option("no_pair", no_pair)
             lam, it = sol.pcg(sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam), 1e-9, 300)
-            assert sol.get_option("last_pair") == (0 if no_pair else 2) and sol.get_option("last_groups") == 1
+            assert sol.get_option("last_pair") == (0 if no_pair else 2), (K, no_pair)
+            assert sol.get_option("last_groups") == (1 if (not no_pair or K >= 37) else 2), (K, no_pair)    # 33..36 one row per lane: two workgroups
             assert int(host(it)[0]) == it_o, (K, no_pair)
             assert rel(host(lam), lam_o) < 1e-9, (K, no_pair)
             res[no_pair] = host(lam).copy()
@@ -1547,4 +1548,62 @@ def test_pipelined_variant(S, C, K, dt, opts):
     lam2, it2 = sol.pcg(dS, dP, dg, tol, 300)
     assert torch.equal(lam1, lam2) and torch.equal(it1, it2)        # deterministic
     sol.check_status()
+    sol.close()
+
+
+def test_f32_hybrid_kernel_every_size_it_serves():
+    """Round 4: fp32 one-workgroup solves of 37 <= K <= 52 knots (14/7) run four two-row waves + four DPP-row waves
+    (pcg_single_f32h_kernel, option f32_hybrid: opt-in, measured equal in time) instead of five or six two-row waves.  Per-row products are the same chains as in the two-row
+    kernel (option no_hybrid), the dot products group differently: against the oracle by check_f32, against the two-row
+    kernel at rounding level, whole solves with the helper blocks' dz, batches and the true warm start included."""
+    from gato_python_amd.solver import Solver
+    S, C = 14, 7
+    for K in (37, 41, 44, 50, 52):
+        s = synth.make_system(S, C, K, seed=500 + K)
+        Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, np.float32)
+        Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+        Pb = co.form_ss(Sb, Pb, S, K)
+        res = {}
+        for nh in (0, 1):
+            sol = make_solver(S, C, K, np.float32)
+            sol.set_option("f32_hybrid", 1 - nh)
+            dS, dP, dg = sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam)
+            lam12, _ = sol.pcg(dS, dP, dg, 0.0, 12)
+            check_pcg(f"f32 hybrid={1 - nh} 14/7/{K} 12 iterations", Sb, Pb, gam, S, K, 0.0, 12, host(lam12))
+            lam, it = sol.pcg(dS, dP, dg, 1e-4, 300)
+            check_pcg(f"f32 hybrid={1 - nh} 14/7/{K} to 1e-4", Sb, Pb, gam, S, K, 1e-4, 300, host(lam), int(host(it)[0]))
+            lam2, it2 = sol.pcg(dS, dP, dg, 1e-4, 300)
+            assert torch.equal(lam, lam2) and torch.equal(it, it2)          # deterministic
+            assert sol.get_option("last_pair") == 1 and sol.get_option("last_groups") == 1
+            res[nh] = (host(lam12).copy(), int(host(it)[0]))
+            if nh == 0 and K in (37, 50):                                   # true warm start through the hybrid
+                sol.set_option("true_warm_start", 1)
+                lam_o, it_o = o.pcg(Sb.astype(np.float64), Pb.astype(np.float64), gam.astype(np.float64), S, K, 1e-12, 300)
+                l0 = (lam_o * (1 + 1e-3 * np.cos(np.arange(S * K)))).astype(np.float32)
+                lam_w, it_w = o.pcg(Sb, Pb, gam, S, K, 1e-4, 300, lam0=l0)
+                lamw, itw = sol.pcg(dS, dP, dg, 1e-4, 300, lam=sol.to_device(l0))
+                assert abs(int(host(itw)[0]) - it_w) <= 2 and rel(host(lamw), lam_o) < 1e-3, (K, int(host(itw)[0]), it_w)
+            sol.close()
+        assert rel(res[0][0], res[1][0]) < 2e-5 and abs(res[0][1] - res[1][1]) <= 1, (K, rel(res[0][0], res[1][0]), res[0][1], res[1][1])
+        # whole solve (assembly images, helper blocks' dz) and a small batch
+        sol = Solver(S, C, K, np.float32)
+        sol.set_option("f32_hybrid", 1)
+        dev = sol.upload_system(s)
+        lam, dz = sol.new(S * K), sol.new(sol.N)
+        dz.fill_(float("nan"))
+        sol.linsys(*dev, 1e-5, 100, s.rho, lam, dz)
+        torch.cuda.synchronize(); sol.check_status()
+        check_solve(f"f32 hybrid whole solve 14/7/{K}", s, S, C, K, np.float32, 1e-5, 100, host(lam), host(dz))
+        sol.close()
+    K, B = 50, 5
+    systems = [synth.make_system(S, C, K, seed=700 + b) for b in range(B)]
+    sol = Solver(S, C, K, np.float32, batch=B)
+    sol.set_option("f32_hybrid", 1)
+    dev = sol.upload_batch(systems)
+    lam, dz, it = sol.new(B * S * K), sol.new(B * sol.N), sol.new(B, torch.int32)
+    sol.linsys_batched(*dev, 1e-5, 100, systems[0].rho, lam, dz, it)
+    torch.cuda.synchronize(); sol.check_status()
+    for b, sysm in enumerate(systems):
+        check_solve(f"f32 hybrid batch system {b}", sysm, S, C, K, np.float32, 1e-5, 100, host(lam)[b * S * K:(b + 1) * S * K],
+                    host(dz)[b * sol.N:(b + 1) * sol.N])
     sol.close()

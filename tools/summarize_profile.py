@@ -99,9 +99,14 @@ traffic = {}
 WL["iiwa_14_7_k16384_f32"] = ("pcg_resident_kernel<float, 14", 16384)
 
 
+SEMI = re.compile(r"pcg_resident_kernel<\w+, \d+, \d+, \d+, \w+, [1-9]")        # XR > 0: the semi-resident instantiations
 for name, (prefix, K) in WL.items():
     for key in fetch:
         want = geom.get(name) or 0
+        # a register-resident and a semi-resident launch can share prefix AND grid (14/7/4096 f64: 128 x 512, 14/7/65536 f64 semi:
+        # 256 x 256): the semi-resident entries take the XR > 0 instantiations only, the others never
+        if key[0].startswith("pcg_resident_kernel") and bool(SEMI.match(key[0])) != (name.endswith("_semi") or name == "iiwa_14_7_k16384_f32"):
+            continue
         helpers = "pcg_single_" in key[0] and want > 0 and key[1] % want == 0 and (key[1] // want - 1) % 8 == 0 and key[1] // want < 200   # + 8 x h helper blocks
         if key[0].startswith(prefix) and (want in (key[1], key[1] // 8 if key[1] % 8 == 0 else -1) or helpers):   # xcd_pack launches an 8x grid
             fv, wv = fetch[key], write.get(key, [])
