@@ -756,7 +756,10 @@ static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int
         const bool dma_ok = !s->true_warm_start && s->ops->pcg_dma_max_knots() > 0 && kp <= s->ops->pcg_dma_max_knots();
         // measured cross-overs against the semi-resident launch: 14/7 f32 K ~ 90 000 (420 MB of S + Pinv), 32/16 f32 K ~ 28 000
         // (690 MB: its semi-resident launch already reads at 6 TB/s)
-        const bool beyond_cache = s->esz == 4 && 2.0 * 3.0 * S * S * (double)K * (double)s->esz > (S > 16 ? 700e6 : 450e6);
+        // (a cluster judges by the LARGEST shard, ceil(K_system / ranks), on every rank: shards differ by a knot and neighbouring
+        //  ranks must not land on different sides of the threshold - ADVICE r3: nothing exercised such a mix)
+        const double K_rule = s->cl.on && s->cl.nranks > 0 ? (double)((s->d.K + s->cl.nranks - 1) / s->cl.nranks) : (double)K;
+        const bool beyond_cache = s->esz == 4 && 2.0 * 3.0 * S * S * K_rule * (double)s->esz > (S > 16 ? 700e6 : 450e6);
         int which = 0;
         if (s->pcg_semi == 1) which = semi_ok ? 1 : 0;
         else if (s->pcg_semi == 2) which = nores_ok ? 2 : 0;

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-python tools/ab_libs.py reps=2 prod build/ab/libgato_prio1.so build/ab/libgato_prio3.so > gpurun_out/r4_ab6.log 2>&1
-tail -5 gpurun_out/r4_ab6.log
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r4_gputests8.log 2>&1
-echo "pytest rc=$?" >> gpurun_out/r4_gputests8.log
-tail -4 gpurun_out/r4_gputests8.log
+export GATO_BENCH_ONE_GPU=1
+timeout -k 10 700 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 5 > gpurun_out/r4_rehearse2.out 2> gpurun_out/r4_rehearse2.err
+echo "rc=$?" >> gpurun_out/r4_rehearse2.err
+tail -c 3500 gpurun_out/r4_rehearse2.out
+tail -5 gpurun_out/r4_rehearse2.err
