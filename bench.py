@@ -440,12 +440,22 @@ def headline(res, name, steps, warmup, traffic, traffic_src, cpu=None, sweep_fil
 
 
 def sweep_summary(entry):
-    """One short record per sweep entry for the headline line (the full entries are earlier stdout lines + the sweep file)."""
-    r = {"us_per_iter": entry.get("pcg_us_per_iter"), "iters_per_s": entry.get("iters_per_s")}
+    """One short record per sweep entry for the headline line (the full entries are earlier stdout lines + the sweep file).
+    Short keys, four significant digits - two dozen entries must fit the 4 KB line: us = us per PCG iteration, ips = iterations/s
+    over whole steps, and the entry's ROOF: hbm = fraction of the 8 TB/s HBM roofline where the launch really streams its
+    matrices every iteration, else (register-resident launches, whose algorithmic GB/s may exceed the HBM peak) gbs = algorithmic
+    GB/s with floor = measured latency floor / production time (products + reductions / hand-offs of the same kernel, live
+    ablation) where the kernel has the timing-only switches."""
+    def sig(x):
+        return float(f"{x:.4g}") if isinstance(x, (int, float)) and x == x else x
+    r = {"us": sig(entry.get("pcg_us_per_iter")), "ips": sig(entry.get("iters_per_s"))}
     if entry.get("roofline_frac") is not None:
-        r["hbm_frac"] = entry["roofline_frac"]
+        r["hbm"] = sig(entry["roofline_frac"])
     elif entry.get("achieved_gbs") is not None:
-        r["alg_gbs"] = entry["achieved_gbs"]
+        r["gbs"] = sig(entry["achieved_gbs"])
+        lf = entry.get("latency_floor")
+        if isinstance(lf, dict) and lf.get("frac_of_floor") is not None:
+            r["floor"] = sig(lf["frac_of_floor"])
     return r
 
 
@@ -585,6 +595,7 @@ def main():
             pass
     out = headline(res, name, args.steps, args.warmup, traffic, traffic_src, cpu, sweep_file)
     if do_sweep:
+        out["sweep_keys"] = "us=us/PCG iteration, ips=iterations/s over whole steps, hbm=fraction of 8 TB/s (launch streams its matrices), gbs=algorithmic GB/s (register-resident), floor=latency floor/production"
         out["sweep"] = {e["workload"]: sweep_summary(e) for e in sweep}
         if sweep_err:
             out["sweep_error"] = sweep_err[:160]
@@ -592,6 +603,7 @@ def main():
         line = dumps_strict(out, LINE_LIMIT)
     except ValueError:                 # never lose the headline to its riders
         out.pop("sweep", None)
+        out.pop("sweep_keys", None)
         line = dumps_strict(out, LINE_LIMIT)
     print(line, flush=True)
 
