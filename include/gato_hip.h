@@ -82,7 +82,12 @@ void *gato_solver_buffer(gato_solver *s, int which);
  * reference's behaviour: lambda restarts from zero, gato_pcg.cuh:303; 1 = d_lambda of gato_pcg /
  * gato_linsys_device is read as the initial guess, r0 = gamma - S lambda0), pcg_variant (0 = the reference's PCG
  * recurrence; 1 = opt-in single-reduction Chronopoulos-Gear recurrence of the resident kernel: one inter-workgroup
- * hand-off per iteration instead of two, same solution to solver tolerance, different rounding), xcd_pack (-1 auto:
+ * hand-off per iteration instead of two, same solution to solver tolerance, different rounding; 2 = opt-in pipelined
+ * recurrence (Ghysels-Vanroose): the two dots of an iteration are published before its two products and collected after
+ * them - measured no faster than 1 on MI355X, see gato_pcg_cg1.hip), coop_launch (1 = the multi-workgroup persistent
+ * launches through hipLaunchCooperativeKernel - what the reference does, gato_pcg.cuh:502-526 - so that the runtime guarantees
+ * their co-residency beside kernels of other streams and processes; +17 us per launch, default 0), mixed_dense / f32_hybrid
+ * (A/B switches of the one-workgroup kernels' lane layouts), xcd_pack (-1 auto:
  * launches of up to 32 workgroups are placed on one XCD - a placement hint, never needed for correctness; 0 off),
  * xcd_sel (which of the eight XCDs hosts such a launch: -1 = measured once per solver and geometry with a millisecond of
  * trial launches before the first one, 0..7 fixed; read-only last_xcd_sel),
