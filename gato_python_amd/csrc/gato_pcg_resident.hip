@@ -1330,6 +1330,7 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         }
     }
     for (int i = tid; i < 2 * (MAXK + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * 4 * ((MAXT + 63) / 64); i += blockDim.x) (&wpart[0][0])[i] = 0.f;       // partials_total_all8 reads all eight waves' slots
     if constexpr (PW)
         for (int i = tid; i < 2 * PWLEN; i += blockDim.x) (&pwin[0][0])[i] = 0.f;
     __syncthreads();
@@ -1395,11 +1396,13 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         float *wp = wpart[epoch & 1];
         partials_store(wp, wave, lane, prod);
         __syncthreads();
-        return partials_total<float, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
+        if constexpr (MAXT <= 512) return partials_total_all8<float>(wp, lane);
+        return partials_total<float, 16>(wp, nwaves, lane);
     };
-    auto put = [&](float *buf, f32x2 v) {
-        if (active) *reinterpret_cast<f32x2 *>(buf + (j + 1) * SP + r0) = v;
-    };
+    // (lanes without rows hold zeros in every vector - their matrix rows are zero - and store them into the zero padding in
+    //  front of knot 0 instead of sitting out behind an exec mask, as in pcg_single_f64m_kernel)
+    const int put_off = active ? (j + 1) * SP + r0 : r0;
+    auto put = [&](float *buf, f32x2 v) { *reinterpret_cast<f32x2 *>(buf + put_off) = v; };
 
     const float *wp_ = PW ? pw_p + win_po : &xs[0][j * SP], *wr_ = PW ? pw_r + win_po : &xs[1][j * SP];
     auto put_private = [&](float *pw, f32x2 v, float g) {
@@ -1413,7 +1416,8 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         partials_store(wp, wave, lane, prod);
         __syncthreads();
         hx = xw[hoff];
-        return partials_total<float, (MAXT <= 512 ? 8 : 16)>(wp, nwaves, lane);
+        if constexpr (MAXT <= 512) return partials_total_all8<float>(wp, lane);
+        return partials_total<float, 16>(wp, nwaves, lane);
     };
 
     f32x2 lam = {0.f, 0.f};
@@ -1476,7 +1480,7 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
             eta_new = block_sum_x(r[0] * rt[0] + r[1] * rt[1], xs[1], hx);
         } else eta_new = block_sum(r[0] * rt[0] + r[1] * rt[1]);
         if (rec) a.eta_hist[it + 1] = (double)eta_new;
-        if (fabsf(eta_new) < tol) { iters = it; break; }                   // :404-411
+        if (__builtin_amdgcn_readfirstlane((int)(fabsf(eta_new) < tol))) { iters = it; break; }                   // :404-411
         const float beta = quotient(eta_new, eta);
         p = rt + beta * p;
         eta = eta_new;
@@ -1627,6 +1631,7 @@ __global__ __launch_bounds__(512) void pcg_single_f32h_kernel(PcgLaunch a)
     }
     for (int i = tid; i < 2 * (MAXK + 2) * SP; i += NT) (&xs[0][0])[i] = 0.f;
     for (int i = tid; i < 2 * W2 * PK * SP; i += NT) (&pwin[0][0])[i] = 0.f;
+    if (tid < 2 * 4 * WT) (&wpart[0][0])[tid] = 0.f;
     __syncthreads();
     // two-row waves: the wave's rows [R0, R1), its private windows (slot 0 = knot jf - 1) and the lane's halo row
     int hoff = 0, hpo = 0, own_po = 0, win_po = 0;
@@ -1687,7 +1692,7 @@ __global__ __launch_bounds__(512) void pcg_single_f32h_kernel(PcgLaunch a)
         __syncthreads();
         hx = xw[two ? hoff : xl_o];
         hy = xw[two ? hoff : xr_o];
-        return partials_total<float, 8>(wp, WT, lane);
+        return partials_total_all8<float>(wp, lane);
     };
     auto put_x = [&](float *buf, f32x2 v) {                            // own entries into an exchange window
         if (active) {
@@ -1763,7 +1768,7 @@ __global__ __launch_bounds__(512) void pcg_single_f32h_kernel(PcgLaunch a)
         put_x(xs[1], rt);
         eta_new = block_sum_x(r[0] * rt[0] + r[1] * rt[1], xs[1], hx, hy);
         if (rec) a.eta_hist[it + 1] = (double)eta_new;
-        if (fabsf(eta_new) < tol) { iters = it; break; }                   // :404-411
+        if (__builtin_amdgcn_readfirstlane((int)(fabsf(eta_new) < tol))) { iters = it; break; }                   // :404-411
         const float beta = quotient(eta_new, eta);
         p = rt + beta * p;
         eta = eta_new;
@@ -2070,10 +2075,12 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 #else
 #define GATO_ST(i) do { } while (0)
 #endif
-    auto block_sum = [&](T prod, int si = 0) -> T {
+    // `which`: the partials buffer of this call site - consecutive block sums alternate between the two (p . upsilon in [0],
+    // r . r~ in [1]), so a wave may store its next partials while a slower one still reads the previous ones
+    auto block_sum = [&](T prod, int si, int which) -> T {
         ++epoch;
         if (abl & 4) return (T)1 + prod * (T)1e-30;
-        T *wp = wpart[epoch & 1];
+        T *wp = wpart[which];
         partials_store(wp, wave, lane, prod);
 #ifdef GATO_F64M_STAMP
         if (st_on) st_[si] = clock64();
@@ -2082,13 +2089,16 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 #ifdef GATO_F64M_STAMP
         if (st_on) st_[si + 1] = clock64();
 #endif
+        if constexpr (WT <= 8) return partials_total_all8<T>(wp, lane);        // (wpart is zeroed at set-up: waves beyond WT add zeros)
         return partials_total<T, (WT <= 8 ? 8 : 16)>(wp, WT, lane);
     };
-    auto put = [&](T *buf, V2 v) {
-        if (active) {
-            if (two) *reinterpret_cast<V2 *>(buf + (j + 1) * SP + r0) = v;      // r0 even, SP even: aligned
-            else buf[(j + 1) * SP + r0] = v[0];
-        }
+    // own entries into the operand window.  Lanes without rows hold zeros in every vector (their matrix rows are zero): they
+    // store them into the zero padding in front of knot 0 instead of sitting out behind an exec mask - no mask, no branch but the
+    // wave-uniform one in the loop
+    const int put_off = active ? (j + 1) * SP + r0 : (r0 < S ? r0 & ~1 : 0);
+    auto put = [&](T *buf, V2 v) {                                               // (1.567 -> 1.537 us per iteration against the masked form)
+        if (two) *reinterpret_cast<V2 *>(buf + put_off) = v;                    // r0 even, SP even: aligned
+        else buf[put_off] = v[0];
     };
     const T *wp_ = &xs[j * SP], *wr_ = wp_;                                      // the lane's window: slot j = left neighbour
 
@@ -2111,7 +2121,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
     put(xs, r);
     __syncthreads();
     V2 rt = times_window(1, wr_, r);                                             // gato_pcg.cuh:316-335
-    T eta = block_sum(r[0] * rt[0] + r[1] * rt[1]), eta_new = (T)0;
+    T eta = block_sum(r[0] * rt[0] + r[1] * rt[1], 0, 1), eta_new = (T)0;
     const bool rec = a.eta_hist && tid == 0 && sys == 0;
     if (rec) a.eta_hist[0] = (double)eta;
     V2 p = rt, ups;
@@ -2126,7 +2136,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         GATO_ST(0);
         ups = (abl & 1) ? p * m[0] : times_window(0, wp_, p);                    // upsilon = S p         (:349-351)
         GATO_ST(1);
-        const T v = block_sum(p[0] * ups[0] + p[1] * ups[1], 2);                 // v = p . upsilon       (:353-357)
+        const T v = block_sum(p[0] * ups[0] + p[1] * ups[1], 2, 0);              // v = p . upsilon       (:353-357)
         GATO_ST(4);
         const T alpha = quotient(eta, v);                                        // :364
         lam += alpha * p;                                                        // :373-377
@@ -2137,10 +2147,10 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         GATO_ST(6);
         rt = (abl & 2) ? r * m[1] : times_window(1, wr_, r);                     // r~ = Pinv r           (:380-381)
         GATO_ST(7);
-        eta_new = block_sum(r[0] * rt[0] + r[1] * rt[1], 8);                     // eta' = r . r~         (:382-394)
+        eta_new = block_sum(r[0] * rt[0] + r[1] * rt[1], 8, 1);                  // eta' = r . r~         (:382-394)
         GATO_ST(10);
         if (rec) a.eta_hist[it + 1] = (double)eta_new;
-        if (fabs(eta_new) < tol) { iters = it; break; }                          // :404-411
+        if (__builtin_amdgcn_readfirstlane((int)(fabs(eta_new) < tol))) { iters = it; break; }   // :404-411 (eta' is the same in every lane)
         const T beta = quotient(eta_new, eta);                                   // :415
         p = rt + beta * p;                                                       // :416-419
         put(xs, p);
