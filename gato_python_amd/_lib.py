@@ -52,7 +52,7 @@ def lib() -> ct.CDLL:
     global _LIB
     if _LIB is None:
         if not os.path.exists(SO_PATH) and "GATO_HIP_LIB" not in os.environ:
-            try:                       # source tree without the built library: compile it (hipcc; a clean build of all shapes is ~3 min at -j8, ~5.5 CPU-minutes); no fallback
+            try:                       # source tree without the built library: compile it (hipcc; a clean build of all shapes is ~3 min at -j8, ~6 CPU-minutes); no fallback
                 build()
             except Exception as e:     # noqa: BLE001
                 raise ImportError(f"{SO_PATH} is missing and building it failed: {e}") from e

@@ -285,6 +285,8 @@ template <typename T, int S>
 int launch_pcg_resident(const PcgLaunch &a, hipStream_t st);
 template <typename T, int S>
 int launch_pcg_resident_dpp(const PcgLaunch &a, hipStream_t st);      // gato_pcg_resident_dpp.hip; called by launch_pcg_resident
+template <typename T, int S>
+int launch_pcg_single(const PcgLaunch &a, bool mr, hipStream_t st);   // gato_pcg_resident_single.hip; called by launch_pcg_resident
 template <typename T, int S> int pcg_dma_max_knots();          // knots per workgroup of the LDS-DMA variant (0: none for this shape)
 template <typename T, int S>
 int launch_pcg_dma(const PcgLaunch &a, hipStream_t st);

@@ -2435,6 +2435,53 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
         }
         return launch_pcg_resident_dpp<T, S>(a, st);
     }
+    // the one-workgroup kernels with two rows per lane (pair = 1: fp32; 2: fp64 mixed rows): a translation unit of their own
+    if (a.pair) return launch_pcg_single<T, S>(a, mr, st);
+    if constexpr (SemiThreads<T, S>::v > 0) {
+        if (a.semi == 1) {
+            constexpr int XT = SemiThreads<T, S>::v;
+            const long long extra_rows = ((long long)a.knots_per_wg - a.threads / S) * S;
+            if (a.batch > 1 || a.threads != XT || a.groups < (mr ? 1 : 2) || a.groups > 256 || a.threads / S < 2 ||
+                extra_rows > (long long)SemiRows<T, S>::v * a.threads || (long long)a.groups * a.knots_per_wg < Kl ||
+                (long long)(a.groups - 1) * a.knots_per_wg >= Kl) {
+                set_error("pcg_resident(semi): bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d)", a.K, a.groups,
+                          a.knots_per_wg, a.threads);
+                return GATO_EINVAL;
+            }
+            if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
+            if (mr) GATO_LAUNCH_P((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v, false, true>), dim3(a.groups), dim3(a.threads), st, a);
+            else GATO_LAUNCH_P((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v>), dim3(a.groups), dim3(a.threads), st, a);
+            GATO_HIP_CHECK(hipGetLastError());
+            if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
+            return GATO_OK;
+        }
+    }
+    if constexpr (NoresThreads<T, S>::v > 0) {
+        if (a.semi == 2) {
+            constexpr int NT = NoresThreads<T, S>::v, NX = NoresRows<T, S>::v;
+            if (a.batch > 1 || a.threads != NT || a.groups < (mr ? 1 : 2) || a.groups > 256 ||
+                (long long)a.knots_per_wg * S > (long long)NX * NT || (long long)a.groups * a.knots_per_wg < Kl ||
+                (long long)(a.groups - 1) * a.knots_per_wg >= Kl) {
+                set_error("pcg_resident(no resident rows): bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d)", a.K,
+                          a.groups, a.knots_per_wg, a.threads);
+                return GATO_EINVAL;
+            }
+            if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
+            if (mr) GATO_LAUNCH_P((pcg_resident_kernel<T, S, NT, 0, false, NX, true, true>), dim3(a.groups), dim3(a.threads), st, a);
+            else GATO_LAUNCH_P((pcg_resident_kernel<T, S, NT, 0, false, NX, true>), dim3(a.groups), dim3(a.threads), st, a);
+            GATO_HIP_CHECK(hipGetLastError());
+            if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
+            return GATO_OK;
+        }
+    }
+    return launch_plain<T, S, false>(a, mr, Kl, st);
+}
+
+#if defined(GATO_RESIDENT_SINGLE_PART)
+// gato_pcg_resident_single.hip: the launches of the one-workgroup two-rows-per-lane kernels (compile time: a third of this file's)
+template <typename T, int S>
+int launch_pcg_single(const PcgLaunch &a, bool mr, hipStream_t st)
+{
     if constexpr (sizeof(T) == 4 && S % 2 == 0 && PairThreads<S>::v > 0) {
         if (a.pair) {
             constexpr int PT = PairThreads<S>::v;
@@ -2486,47 +2533,15 @@ int launch_pcg_resident(const PcgLaunch &a0, hipStream_t st)
             return GATO_OK;
         }
     }
-    if constexpr (SemiThreads<T, S>::v > 0) {
-        if (a.semi == 1) {
-            constexpr int XT = SemiThreads<T, S>::v;
-            const long long extra_rows = ((long long)a.knots_per_wg - a.threads / S) * S;
-            if (a.batch > 1 || a.threads != XT || a.groups < (mr ? 1 : 2) || a.groups > 256 || a.threads / S < 2 ||
-                extra_rows > (long long)SemiRows<T, S>::v * a.threads || (long long)a.groups * a.knots_per_wg < Kl ||
-                (long long)(a.groups - 1) * a.knots_per_wg >= Kl) {
-                set_error("pcg_resident(semi): bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d)", a.K, a.groups,
-                          a.knots_per_wg, a.threads);
-                return GATO_EINVAL;
-            }
-            if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-            if (mr) GATO_LAUNCH_P((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v, false, true>), dim3(a.groups), dim3(a.threads), st, a);
-            else GATO_LAUNCH_P((pcg_resident_kernel<T, S, XT, 0, false, SemiRows<T, S>::v>), dim3(a.groups), dim3(a.threads), st, a);
-            GATO_HIP_CHECK(hipGetLastError());
-            if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
-            return GATO_OK;
-        }
-    }
-    if constexpr (NoresThreads<T, S>::v > 0) {
-        if (a.semi == 2) {
-            constexpr int NT = NoresThreads<T, S>::v, NX = NoresRows<T, S>::v;
-            if (a.batch > 1 || a.threads != NT || a.groups < (mr ? 1 : 2) || a.groups > 256 ||
-                (long long)a.knots_per_wg * S > (long long)NX * NT || (long long)a.groups * a.knots_per_wg < Kl ||
-                (long long)(a.groups - 1) * a.knots_per_wg >= Kl) {
-                set_error("pcg_resident(no resident rows): bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d)", a.K,
-                          a.groups, a.knots_per_wg, a.threads);
-                return GATO_EINVAL;
-            }
-            if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
-            if (mr) GATO_LAUNCH_P((pcg_resident_kernel<T, S, NT, 0, false, NX, true, true>), dim3(a.groups), dim3(a.threads), st, a);
-            else GATO_LAUNCH_P((pcg_resident_kernel<T, S, NT, 0, false, NX, true>), dim3(a.groups), dim3(a.threads), st, a);
-            GATO_HIP_CHECK(hipGetLastError());
-            if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
-            return GATO_OK;
-        }
-    }
-    return launch_plain<T, S, false>(a, mr, Kl, st);
+    set_error("pcg_resident: no one-workgroup two-rows-per-lane kernel for this shape and type (pair=%d)", a.pair);
+    return GATO_EINVAL;
 }
-
-#ifndef GATO_RESIDENT_DPP_PART
+#define X(S_, C_)                                                          \
+    template int launch_pcg_single<float, S_>(const PcgLaunch &, bool, hipStream_t); \
+    template int launch_pcg_single<double, S_>(const PcgLaunch &, bool, hipStream_t);
+GATO_SHAPES(X)
+#undef X
+#elif !defined(GATO_RESIDENT_DPP_PART)
 #define X(S_, C_)                                                      \
     template int pcg_resident_plan<float, S_>(PcgPlan *);              \
     template int pcg_resident_plan<double, S_>(PcgPlan *);             \

@@ -8,9 +8,9 @@ S=${1:-14}; C=${2:-7}; shift 2 2>/dev/null
 OBJ=${OBJ:-/tmp/gato_dev}; OUT=${OUT:-libgato_hip_dev.so}
 mkdir -p $OBJ ../../build/ab
 pids=()
-for f in gato_capi gato_assembly gato_pcg_resident gato_pcg_resident_dpp gato_pcg_cg1 gato_pcg_stream gato_pcg_dma; do
+for f in gato_capi gato_assembly gato_pcg_resident gato_pcg_resident_dpp gato_pcg_resident_single gato_pcg_cg1 gato_pcg_stream gato_pcg_dma; do
   if [ ! -f $OBJ/$f.o ] || [ $f.hip -nt $OBJ/$f.o ] || [ gato_common.h -nt $OBJ/$f.o ] || [ gato_pcg_device.h -nt $OBJ/$f.o ] \
-     || { [ $f = gato_pcg_resident_dpp ] && [ gato_pcg_resident.hip -nt $OBJ/$f.o ]; }; then
+     || { { [ $f = gato_pcg_resident_dpp ] || [ $f = gato_pcg_resident_single ]; } && [ gato_pcg_resident.hip -nt $OBJ/$f.o ]; }; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall "-DGATO_SHAPES(X)=X($S,$C)" "$@" -c $f.hip -o $OBJ/$f.o &
     pids+=($!)
   fi
