@@ -1818,10 +1818,12 @@ __global__ __launch_bounds__(512) void pcg_single_f32h_kernel(PcgLaunch a)
 // products: 126 reads on three SIMDs (two-row wave 21 + 63, one-row wave 21 + 21), 84 on the fourth.  Changes:
 //  (1) DR: the one-row waves own 16-lane DPP rows (one knot per row, lanes S..15 idle, row_times_dpp: the operand window comes
 //      from the neighbouring lanes' registers, 2 eight-byte LDS reads per product instead of 21 sixteen-byte ones) and FOUR waves
-//      hold two rows per lane, one per SIMD beside one DPP wave: 81 + 2 reads per SIMD and iteration on all four.  The lanes the
-//      DPP rows leave idle are paid for by LDS: K2MAX knots x S / 2 two-row lanes keep Pinv there, less NPR columns that stay in
-//      registers so that it fits (14/7: 34 knots = 238 lanes x 39 pairs + windows = 160.7 KB of 163.8).  Same per-row summation
-//      order as before (left to right): the same bits.
+//      hold two rows per lane, one per SIMD beside one DPP wave: the same reads per SIMD and iteration on all four.  The lanes
+//      the DPP rows leave idle are paid for by LDS: K2MAX knots x S / 2 two-row lanes keep the ODD columns of S and of Pinv there
+//      (the even ones in registers - see m[] below: either product reads 3S/2 windows + 3S/2 pairs, one read per two packed-row
+//      FMAs), less Pinv's last NPR odd columns, which stay in registers so that it fits (14/7: 34 knots = 238 lanes + 1 slot of
+//      zeros, x 41 pairs x 16 B = 156,784 B + one window 5,824 + partial sums 512 = 163,120 of 163,840 B).  Same per-row
+//      summation order as before (left to right): the same bits.
 //  (2) the Pinv pairs in LDS through base registers + 16-bit immediate offsets (the compiler gave every column beyond the offset
 //      range an address register of its own: 20 VGPRs);
 //  (3) the order of LDS reads and FMAs of the two-row products is PINNED (sched_group_barrier: DEPTH reads first, then reads and
