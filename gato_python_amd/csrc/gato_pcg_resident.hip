@@ -1834,6 +1834,9 @@ __global__ __launch_bounds__(512) void pcg_single_f32h_kernel(PcgLaunch a)
 // Measured and not kept (same box, tools/ab_libs.py): block sums on the matrix core (two v_mfma_f64_16x16x4 with B = ones per
 // wave sum + every lane adding the eight wave totals: 1.94 -> 2.04 us per iteration), the divisor-only half of beta = eta' / eta
 // formed during the Pinv product (1.835 -> 1.833), Pinv pairs read before the barrier in front of the Pinv product.
+#ifndef GATO_F64M_DEV_ABL
+#define GATO_F64M_DEV_ABL 0   // A/B builds only (tools/devbuild.sh -DGATO_F64M_DEV_ABL=8: the loop without its two window barriers, timing only)
+#endif
 #ifndef GATO_F64M_D0
 #define GATO_F64M_D0 8      // reads in flight: two-row lanes, S product (21 reads, 84 FMAs)
 #endif
@@ -2529,7 +2532,7 @@ int launch_pcg_single(const PcgLaunch &a, bool mr, hipStream_t st)
             else if (abl == 3) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 3, DR, K2, NPR>), grid, block, 0, st, a);
             else if (abl == 4) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 4, DR, K2, NPR>), grid, block, 0, st, a);
             else if (abl == 15) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 15, DR, K2, NPR>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 0, DR, K2, NPR>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, GATO_F64M_DEV_ABL, DR, K2, NPR>), grid, block, 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;
