@@ -202,7 +202,20 @@ __device__ __forceinline__ void xcd_knot_map(int &sys, int &kidx)
 
 // ---- A2b: Schur blocks, block-Jacobi main blocks, gamma (gato_schur.cuh:13-460) -----------------
 // waves per SIMD the register allocation must leave room for (one-wave workgroups: latency-bound launches want many knots in flight)
-template <typename T, int S> struct AsmWaves { static constexpr int v = S <= 16 ? (sizeof(T) == 8 ? 4 : 5) : 1; };
+#ifndef GATO_SCHUR_WAVES_F64
+#define GATO_SCHUR_WAVES_F64 4
+#endif
+#ifndef GATO_SCHUR_WAVES_F32
+#define GATO_SCHUR_WAVES_F32 5
+#endif
+#ifndef GATO_GATHER_WAVES_F64
+#define GATO_GATHER_WAVES_F64 1
+#endif
+#ifndef GATO_GATHER_WAVES_F32
+#define GATO_GATHER_WAVES_F32 1
+#endif
+template <typename T, int S> struct AsmWaves { static constexpr int v = S <= 16 ? (sizeof(T) == 8 ? GATO_SCHUR_WAVES_F64 : GATO_SCHUR_WAVES_F32) : 1; };
+template <typename T, int S> struct GatherWaves { static constexpr int v = S <= 16 ? (sizeof(T) == 8 ? GATO_GATHER_WAVES_F64 : GATO_GATHER_WAVES_F32) : 1; };
 
 template <typename T, int S, int C>
 __global__ __launch_bounds__(WAVE, (AsmWaves<T, S>::v)) void schur_kernel(const T *__restrict__ Gd, const T *__restrict__ Ginv,
@@ -450,7 +463,7 @@ __device__ __forceinline__ int row_of_entry(const int *ptr, int nrows, int e)
 // two wavefronts then invert Q_k and R_k from LDS (what invert_G_kernel does after a round trip through HBM).
 // Same arithmetic and same destination per entry as the reference.
 template <typename T, int S, int C, int NT>
-__global__ __launch_bounds__(NT) void gather_kernel(const int *__restrict__ G_row, const int *__restrict__ G_col,
+__global__ __launch_bounds__(NT, (GatherWaves<T, S>::v)) void gather_kernel(const int *__restrict__ G_row, const int *__restrict__ G_col,
                                                     const T *__restrict__ G_val, const int *__restrict__ C_row,
                                                     const int *__restrict__ C_col, const T *__restrict__ C_val, int K, T rho,
                                                     T *__restrict__ Gd, T *__restrict__ Cd, T *__restrict__ Ginv, BatchStride bs)
