@@ -60,6 +60,7 @@ static inline int gato_pyseq_pack(PyObject *obj, char kind, void **data, Py_ssiz
             char c;
             Py_ssize_t cnt, i;
             void *buf;
+            int ovf = 0;
             while (*f == '@' || *f == '=' || *f == '<') ++f;
             c = *f;
             if (vw.ndim == 1 && f[1] == '\0' && (c == 'f' || c == 'd' || c == 'i' || c == 'l' || c == 'q' || c == 'I' || c == 'L' || c == 'Q') &&
@@ -72,7 +73,12 @@ static inline int gato_pyseq_pack(PyObject *obj, char kind, void **data, Py_ssiz
         const SRC_T *s_ = (const SRC_T *)vw.buf;                                                                       \
         if (kind == 'f') for (i = 0; i < cnt; ++i) ((float *)buf)[i] = (float)s_[i];                                   \
         else if (kind == 'd') for (i = 0; i < cnt; ++i) ((double *)buf)[i] = (double)s_[i];                            \
-        else for (i = 0; i < cnt; ++i) ((int *)buf)[i] = (int)s_[i];                                                   \
+        else for (i = 0; i < cnt; ++i) {                                                                               \
+            const SRC_T x_ = s_[i];                                                                                    \
+            const int y_ = (int)x_;                                                                                    \
+            if ((SRC_T)y_ != x_ || ((x_ < (SRC_T)0) != (y_ < 0))) ovf = 1;      /* as the list path: no silent wrap */ \
+            ((int *)buf)[i] = y_;                                                                                      \
+        }                                                                                                              \
     } while (0)
                 if ((c == 'f' && kind == 'f') || (c == 'd' && kind == 'd') || (c == 'i' && kind == 'i')) memcpy(buf, vw.buf, (size_t)cnt * esz);
                 else if (c == 'f') GATO_PYSEQ_CONV(float);
@@ -85,6 +91,7 @@ static inline int gato_pyseq_pack(PyObject *obj, char kind, void **data, Py_ssiz
                 else GATO_PYSEQ_CONV(unsigned int);
 #undef GATO_PYSEQ_CONV
                 PyBuffer_Release(&vw);
+                if (ovf) { free(buf); PyErr_SetString(PyExc_OverflowError, "index does not fit 32 bits"); return -1; }
                 *data = buf; *n = cnt;
                 return 0;
             }

@@ -210,7 +210,12 @@ def test_fast_list_conversion_matches_the_numpy_narrowing():
     assert np.array_equal(np.frombuffer(fs.pack(range(7), "i"), np.int32), np.arange(7, dtype=np.int32))
     assert len(fs.pack([], "f")) == 0
     for bad, kind, exc in (("abc", "f", TypeError), ([1.5], "i", TypeError), ([2 ** 40], "i", OverflowError), ([[1.0]], "f", TypeError),
-                           (3.0, "f", TypeError), ([None], "d", TypeError), (np.ones(3), "i", TypeError)):
+                           (3.0, "f", TypeError), ([None], "d", TypeError), (np.ones(3), "i", TypeError),
+                           (np.asarray([1, 2 ** 40]), "i", OverflowError), (np.asarray([2 ** 31], np.uint32), "i", OverflowError),
+                           (np.asarray([-1, 5], np.int64), "f", None)):
+        if exc is None:
+            assert np.array_equal(np.frombuffer(fs.pack(bad, kind), np.float32), bad.astype(np.float32))
+            continue
         with pytest.raises(exc):
             fs.pack(bad, kind)
     out = fs.unpack(np.asarray([1.5, -2.25, 3e-40], np.float32), "f")
