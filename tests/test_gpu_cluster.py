@@ -153,6 +153,29 @@ def test_cluster_semi_resident_shards(S, C, K, semi):
         x.close()
 
 
+def test_cluster_neighbouring_ranks_on_different_launch_variants():
+    """Shards differ by a knot when K is not a multiple of the ranks, and a launch-capacity boundary can fall between them: here
+    rank 0 (6481 knots) takes the semi-resident launch, rank 1 (6480 = 120 workgroups x 54 knots of 768 threads) the resident one.  Both
+    are pcg_resident_kernel<..., MR> with the same hand-off protocol; the solve must not care."""
+    from gato_python_amd.solver import Solver
+    S, C, K, R, dt = 14, 7, 12961, 2, np.float32
+    Sb, Pb, gam = oracle_blocks(S, C, K, dt, seed=5)
+    lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, 1e-4, 60)
+    sols = [Solver(S, C, K, dt) for _ in range(R)]
+    for x in sols:
+        x.set_option("max_workgroups", 120)               # two ranks share this GPU
+    dS, dP, dg = sols[0].to_device(Sb), sols[0].to_device(Pb), sols[0].to_device(gam)
+    lam, its = run_cluster_lockstep(sols, dS, dP, dg, 1e-4, 60)
+    for x in sols:
+        x.check_status()
+    semi = [x.get_option("last_semi") for x in sols]
+    assert knot_ranges(K, R) == [(0, 6481), (6481, 12961)] and semi[0] != 0 and semi[1] == 0, (knot_ranges(K, R), semi)
+    assert len(set(its)) == 1 and abs(its[0] - it_o) <= 1, (its, it_o)
+    f32_judged(f"cluster of a semi-resident and a resident shard {S}/{C}/{K}", lam.cpu().numpy(), lam_o, converged_f64(Sb, Pb, gam, S, K))
+    for x in sols:
+        x.close()
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
