@@ -953,7 +953,9 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         // (batches only: every system's workgroup does its own dz and a launch of 25 600 one-wave workgroups goes away; for
         //  ONE system the single workgroup is as latency bound as that launch was - measured 11 us in the epilogue against
         //  5.3 us + a launch gap - unless asked for with no_fuse_dz = -1)
-        if (s->fz.dz && (s->no_fuse_dz < 0 || (!s->no_fuse_dz && batch > 1)) && groups == 1 && !cg1 && s->plan_pair != 1 && !a.semi && !s->stamp_pcg) {
+        // (fp32 two-rows-per-lane kernel: its epilogue exists for batches; the opt-in hybrid kernel has none)
+        if (s->fz.dz && (s->no_fuse_dz < 0 || (!s->no_fuse_dz && batch > 1)) && groups == 1 && !cg1 &&
+            (s->plan_pair != 1 || (batch > 1 && !s->f32_hybrid)) && !a.semi && !s->stamp_pcg) {
             a.dz_Ginv = s->fz.Ginv; a.dz_Cd = s->fz.Cd; a.dz_g = s->fz.g; a.dz = s->fz.dz; a.C = s->d.C;
             s->dz_fused = 1;
         }

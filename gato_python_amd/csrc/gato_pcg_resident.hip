@@ -1499,6 +1499,66 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         __syncthreads();
         if (tid == 0) __hip_atomic_store((gi32 *)a.dz_flag, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // ---- dz back-substitution in the same launch (batches: one workgroup per system), as in pcg_single_f64m_kernel: formulas and
+    // accumulation order of dz_kernel (gato_assembly.hip; gato_schur.cuh:758-867, D2 fixed), row by row: bit-identical results.
+    if (a.dz != nullptr && !a.dz_helpers) {
+        const int Cn = a.C, n = S + Cn, k = j;
+        const size_t gs = (size_t)(S * S + Cn * Cn), cs = (size_t)(S * S + S * Cn), Nn = (size_t)n * K - Cn;
+        const float *__restrict__ Gi = static_cast<const float *>(a.dz_Ginv) + sys * (gs * K - (size_t)Cn * Cn);
+        const float *__restrict__ Cdn = static_cast<const float *>(a.dz_Cd) + sys * (cs * (K - 1));
+        const float *__restrict__ gv = static_cast<const float *>(a.dz_g) + sys * Nn;
+        float *__restrict__ dzo = static_cast<float *>(a.dz) + sys * Nn;
+        const bool last = k == K - 1;
+        __syncthreads();                                                     // every wave has left the loop: both windows are free
+        put(xs[0], lam);                                                     // lambda window
+        __syncthreads();
+        float tx[2] = {0.f, 0.f}, tu[2] = {0.f, 0.f};
+        if (active) {
+            for (int q = 0; q < 2; ++q) {
+                const int rr = r0 + q;
+                if (!last) {
+                    const float *__restrict__ A = Cdn + (size_t)k * cs;
+                    const float *lp = &xs[0][(j + 2) * SP];                  // lambda_{k+1}
+                    float res = 0.f;
+#pragma unroll
+                    for (int t = 0; t < S; ++t) res = gato::fmaT(A[rr * S + t], lp[t], res);          // A_k^T lambda_{k+1}   :833-838
+                    tx[q] = gv[(size_t)k * n + rr] - (lam[q] + res);                                  // :841-852
+                    if (rr < Cn) {
+                        const float *__restrict__ B = A + S * S;
+                        float rb = 0.f;
+#pragma unroll
+                        for (int t = 0; t < S; ++t) rb = gato::fmaT(B[rr * S + t], lp[t], rb);        // B_k^T lambda_{k+1}   :784-789
+                        tu[q] = gv[(size_t)k * n + S + rr] - rb;                                      // :792-796
+                    }
+                } else tx[q] = gv[(size_t)k * n + rr] - lam[q];                                       // last state row (D2)
+                xs[1][(j + 1) * SP + rr] = tx[q];
+            }
+        }
+        __syncthreads();                                                     // lambda_{k+1} has been read everywhere
+        if (active && !last) {
+            for (int q = 0; q < 2; ++q)
+                if (r0 + q < Cn) xs[0][(j + 1) * SP + r0 + q] = tu[q];
+        }
+        __syncthreads();
+        if (active) {
+            const float *__restrict__ Qi = Gi + (size_t)k * gs;
+            const float *tv = &xs[1][(j + 1) * SP];
+            for (int q = 0; q < 2; ++q) {
+                const int rr = r0 + q;
+                float res = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < S; ++cc) res = gato::fmaT(Qi[rr + cc * S], tv[cc], res);        // Q_k^-1 (...)         :856-865
+                dzo[(size_t)k * n + rr] = res;
+                if (!last && rr < Cn) {
+                    const float *__restrict__ Ri = Qi + S * S;
+                    const float *uv = &xs[0][(j + 1) * SP];
+                    float ru = 0.f;
+                    for (int cc = 0; cc < Cn; ++cc) ru = gato::fmaT(Ri[rr + cc * Cn], uv[cc], ru);    // R_k^-1 (...)         :799-808
+                    dzo[(size_t)k * n + S + rr] = ru;
+                }
+            }
+        }
+    }
     if (tid == 0) {
         // a helper block that gave up on this launch (see one_system_helper) left dz rows unwritten: in-band, as a hand-off time-out
         const bool dz_lost = a.dz_helpers && a.dz != nullptr && a.batch <= 1 &&

@@ -1385,6 +1385,35 @@ def test_dz_in_the_pcg_epilogue_is_bit_identical_to_the_dz_launch(S, C, K, dt, B
                 two_orders=K <= 2)
 
 
+@pytest.mark.parametrize("K,B,shared", [(50, 6, 0), (50, 6, 1), (37, 3, 0), (73, 2, 0), (3, 4, 0), (1, 2, 0)])
+def test_dz_in_the_fp32_two_row_epilogue_of_a_batch_is_bit_identical_to_the_dz_launch(K, B, shared):
+    """Batches through pcg_single_f32x2_kernel (one workgroup per system, two rows per lane, wave-private or shared windows): the
+    dz back-substitution rides in the launch's epilogue as in the fp64 kernel - the bits of dz_kernel, no dz launch."""
+    from gato_python_amd.solver import Solver
+    S, C, dt = 14, 7, np.float32
+    systems = [system(S, C, K, seed=20 + i) if K > 1 else synth.blocks_to_csr(*synth.make_blocks(S, C, 1, 20 + i, False)) for i in range(B)]
+    res = {}
+    for nofuse in (0, 1):
+        sol = Solver(S, C, K, dt, batch=B)
+        sol.set_option("no_fuse_dz", nofuse)
+        sol.set_option("shared_windows", shared)
+        dev = sol.upload_batch(systems)
+        lam, dz = sol.new(B * S * K), sol.new(B * sol.N)
+        dz.fill_(float("nan"))
+        sol.linsys_batched(*dev, 1e-5, 60, systems[0].rho, lam, dz)
+        sol.check_status()
+        assert sol.get_option("last_pair") == 1 and sol.get_option("last_dz_fused") == (0 if nofuse else 1)
+        res[nofuse] = (host(lam).copy(), host(dz).copy())
+        sol.close()
+    assert np.isfinite(res[0][1]).all()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    if K > 2:
+        n_dz = (S + C) * K - C
+        for b in (0, B - 1):
+            check_solve(f"fp32 two-row epilogue dz 14/7/{K} system {b} of {B}", systems[b], S, C, K, dt, 1e-5, 60,
+                        res[0][0][b * S * K:(b + 1) * S * K], res[0][1][b * n_dz:(b + 1) * n_dz])
+
+
 def test_mixed_rows_kernel_both_layouts():
     """Round 4: the one-row waves of pcg_single_f64m_kernel own 16-lane DPP rows (default; four two-row waves beside them, even
     columns of S and Pinv in registers, odd ones in LDS) - against round 2's dense layout (option mixed_dense) on the same
