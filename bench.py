@@ -508,9 +508,9 @@ def run_sweep(args, torch, emit):
         r["workload"] += tag
         r["max_iters"] = 20
         emit(r)
-    # fp64 in the same regime: the ring with 8-byte slots (not auto-selected: within 3 % of the semi-resident
-    # launch), the semi-resident launch (auto) and the streaming kernels
-    for mode, semi, tag in ((None, 3, "_ring"), (None, 1, "_semi"), (2, None, "_streaming")):
+    # fp64 in the same regime: auto = the ring with 8-byte slots (from 550 MB of S + Pinv: measured cross-over against the
+    # semi-resident launch, profiles/r05_ring_crossover.log), beside it the semi-resident launch and the streaming kernels
+    for mode, semi, tag in ((None, None, ""), (None, 1, "_semi"), (2, None, "_streaming")):
         r, _ = run_single("iiwa_14_7_k65536_f64", 3, 1, torch, pcg_mode=mode, pcg_reps=5, max_iters=20, pcg_semi=semi)
         annotate(r, "iiwa_14_7_k65536_f64" + tag)
         r["workload"] += tag

@@ -173,7 +173,7 @@ struct gato_solver {
         unsigned long long *local;
         unsigned long long *peer[GATO_MAX_RANKS];
         bool opened[GATO_MAX_RANKS];
-        size_t bytes, flat_off;
+        size_t bytes, flat_off, lam_off;
         unsigned xepoch;
         int last_flat;
         int mem_kind;                 // 0 uncached, 1 fine-grained, 2 plain hipMalloc
@@ -749,17 +749,19 @@ static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int
         const int xt = s->plan.semi_threads, nt = s->plan.nores_threads;
         const bool semi_ok = xt > 0 && (long long)(kp - xt / S) * S <= (long long)s->plan.semi_rows * xt;
         const bool nores_ok = nt > 0 && (long long)kp * S <= (long long)s->plan.nores_rows * nt;
-        // the LDS-DMA ring (option pcg_semi = 3; auto: fp32 once S and Pinv together are well past the 256 MB Infinity Cache,
-        // i.e. the re-read block rows come from HBM - measured cross-over at 14/7 fp32: K ~ 90 000 = 420 MB; below that the
-        // semi-resident launch is served by the caches and wins, and in fp64 the ring's 4-row tiles are step-bound)
-        // (K = the knots of THIS launch: a rank's shard in a cluster - what matters is what one GPU streams per product)
+        // the LDS-DMA ring (option pcg_semi = 3; auto: once the bytes of S and Pinv that ONE launch streams per product are well past
+        // the 256 MB Infinity Cache, i.e. the re-read block rows come from HBM; below that the semi-resident launch is served by the
+        // caches and wins).  Measured cross-overs against the semi-resident launch (tools/ring_crossover.py, profiles/r05_ring_crossover.log):
+        // 14/7 f32 K ~ 90 000 (420 MB), 32/16 f32 K ~ 28 000 (690 MB: its semi-resident launch already reads at 6 TB/s), 14/7 f64
+        // between K = 49 152 (462 MB: semi 79.6 / ring 82.9 us per iteration) and K = 65 536 (617 MB: 107.7 / 104.6; driver sweep of
+        // round 4: 107.9 / 97.3) - the fp64 ring serves up to 256 knots per workgroup, so auto takes it from 550 MB up to K = 65 536.
+        // (K = the knots of THIS launch: a rank's shard in a cluster - what matters is what one GPU streams per product.  A cluster
+        //  judges by the LARGEST shard, ceil(K_system / ranks), on every rank: shards differ by a knot and neighbouring ranks must
+        //  not land on different sides of the threshold.)
         const bool dma_ok = !s->true_warm_start && s->ops->pcg_dma_max_knots() > 0 && kp <= s->ops->pcg_dma_max_knots();
-        // measured cross-overs against the semi-resident launch: 14/7 f32 K ~ 90 000 (420 MB of S + Pinv), 32/16 f32 K ~ 28 000
-        // (690 MB: its semi-resident launch already reads at 6 TB/s)
-        // (a cluster judges by the LARGEST shard, ceil(K_system / ranks), on every rank: shards differ by a knot and neighbouring
-        //  ranks must not land on different sides of the threshold - ADVICE r3: nothing exercised such a mix)
         const double K_rule = s->cl.on && s->cl.nranks > 0 ? (double)((s->d.K + s->cl.nranks - 1) / s->cl.nranks) : (double)K;
-        const bool beyond_cache = s->esz == 4 && 2.0 * 3.0 * S * S * K_rule * (double)s->esz > (S > 16 ? 700e6 : 450e6);
+        const double ring_from = S > 16 ? 700e6 : (s->esz == 8 ? 550e6 : 450e6);
+        const bool beyond_cache = 2.0 * 3.0 * S * S * K_rule * (double)s->esz > ring_from;
         int which = 0;
         if (s->pcg_semi == 1) which = semi_ok ? 1 : 0;
         else if (s->pcg_semi == 2) which = nores_ok ? 2 : 0;
@@ -777,10 +779,14 @@ static int plan_resident_k(gato_solver *s, int K, int *groups, int *threads, int
 }
 
 // Geometry of the single-reduction variant: a workgroup's lanes cover its own knots plus one ghost-lane knot per side.
-static int plan_cg1(gato_solver *s, int *groups, int *threads, int *kpw)
+static int plan_cg1_k(gato_solver *s, int K, int *groups, int *threads, int *kpw);
+static int plan_cg1(gato_solver *s, int *groups, int *threads, int *kpw) { return plan_cg1_k(s, s->d.K, groups, threads, kpw); }
+// K = knots the launch works on (the system's, or one rank's shard of it)
+static int plan_cg1_k(gato_solver *s, int K, int *groups, int *threads, int *kpw)
 {
-    const int S = s->d.S, K = s->d.K;
-    const int max_wg = s->num_cus < 256 ? s->num_cus : 256;
+    const int S = s->d.S;
+    int max_wg = s->num_cus < 256 ? s->num_cus : 256;
+    if (s->max_workgroups > 0 && s->max_workgroups < max_wg) max_wg = s->max_workgroups;   // CUs this solver may count on
     const int maxT = s->ops->pcg_cg1_max_threads();
     int t = s->pcg_threads > 0 ? (s->pcg_threads + 63) / 64 * 64 : 0;
     if (t > maxT) t = maxT;
@@ -865,13 +871,20 @@ static int calibrate_xcd(gato_solver *s, const PcgLaunch &a0, bool cg1, hipStrea
     return GATO_OK;
 }
 
+static bool stream_is_capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+    return cap != hipStreamCaptureStatusNone;
+}
+
 static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
                    double exit_tol, int max_iters, int *d_iters, int batch, hipStream_t st)
 {
     int groups = 0, threads = 0, kpw = 0;
     int mode = s->pcg_mode;
-    // pcg_variant: 1 = single-reduction recurrence, 2 = pipelined recurrence (both opt-in, gato_pcg_cg1.hip; same launch geometry)
-    const bool cg1 = (s->pcg_variant == 1 || s->pcg_variant == 2) && mode != GATO_PCG_STREAMING && !s->true_warm_start &&
+    // pcg_variant: 1 = single-reduction recurrence (opt-in, gato_pcg_cg1.hip)
+    const bool cg1 = s->pcg_variant == 1 && mode != GATO_PCG_STREAMING && !s->true_warm_start &&
                      plan_cg1(s, &groups, &threads, &kpw) != 0 && (batch == 1 || groups == 1);
     const bool fits = cg1 || plan_resident(s, &groups, &threads, &kpw) != 0;
     if (cg1) s->plan_pair = 0;
@@ -888,12 +901,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         // dz flag of the helper blocks (it would already equal the launch id: dz from an unfinished lambda).  So while the
         // stream is being captured the helper blocks do not do dz (the dz launch of its own follows), and a launch that needs
         // epochs is refused - the streaming kernels (pcg_mode = 2) replay correctly.
-        bool capturing = false;
-        {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
-            capturing = cap != hipStreamCaptureStatusNone;
-        }
+        const bool capturing = stream_is_capturing(st);
         if (capturing && !s->tuning && (groups > 1 || s->cl.on)) {
             set_error("pcg: a persistent launch of %d workgroups cannot be captured into a graph (its hand-off epochs are launch "
                       "arguments: a replay would read stale granules); capture the streaming kernels (option pcg_mode = 2) "
@@ -910,7 +918,6 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.shared_windows = s->shared_windows;
         a.mixed_dense = s->mixed_dense;
         a.coop = s->coop_launch && groups > 1 && batch == 1 && !cg1;      // (the single-reduction kernel keeps the plain launch)
-        a.pipelined = cg1 && s->pcg_variant == 2;
         a.f32_hybrid = s->f32_hybrid;
         // (every lane of the launch loads rows 2 tid, 2 tid + 1 resp. its own row: all of them must lie inside a column of the image)
         if (s->img_fresh && !s->no_image && batch == 1 && d_S == s->Sbd && d_Pinv == s->Pbd &&
@@ -1601,7 +1608,9 @@ extern "C" int gato_cluster_create(gato_solver *s, int rank, int nranks, void *i
     s->cl.rank = rank; s->cl.nranks = nranks; s->cl.k0 = k0; s->cl.k1 = k1;
     // two-level area (2 parities), then the flat area: a slot for each of up to 256 workgroups of the whole cluster
     s->cl.flat_off = align_up((size_t)2 * pcg_xslot_granules(s->d.S, (int)s->esz), 16);
-    const size_t need = (s->cl.flat_off + (size_t)2 * 256 * pcg_slot_granules(s->d.S, (int)s->esz)) * 8;
+    // ... then the lambda ghost block a rank receives from its right neighbour at the end of a launch (cluster_lambda_ghost)
+    s->cl.lam_off = s->cl.flat_off + (size_t)2 * 256 * pcg_flat_slot_granules(s->d.S, (int)s->esz);
+    const size_t need = (s->cl.lam_off + (size_t)pcg_lamghost_granules(s->d.S, (int)s->esz)) * 8;
     s->cl.bytes = need < 65536 ? 65536 : align_up(need, 65536);
     if ((rc = cluster_alloc(s))) return rc;
     s->cl.peer[rank] = s->cl.local;
@@ -1676,17 +1685,48 @@ extern "C" int gato_cluster_fits(gato_solver *s, int *groups, int *threads)
     return GATO_OK;
 }
 
+// Single-reduction recurrence in a cluster (option pcg_variant = 1): EVERY rank must be able to run it - its knots fit one launch
+// of pcg_cg1_kernel<..., MR> and every workgroup of the cluster owns at least two knots (the exchange carries the first / last two
+// blocks of w) - or every rank takes the default recurrence: each rank derives every rank's geometry from the same rule (same
+// device type and options on all ranks, as for the flat exchange).  1 = variant 1 runs; geometry of THIS rank, and the flat
+// exchange's numbering (total <= 256 workgroups) if it applies.
+static int cluster_plan_cg1(gato_solver *s, int *groups, int *threads, int *kpw, int *flat_total, int *flat_base)
+{
+    if (s->pcg_variant != 1 || s->true_warm_start || s->pcg_mode == GATO_PCG_STREAMING) return 0;
+    int total = 0, base = 0;
+    for (int r = 0; r < s->cl.nranks; ++r) {
+        int k0 = 0, k1 = 0, g = 0, t = 0, kp = 0;
+        gato_cluster_knot_range(s->d.K, r, s->cl.nranks, &k0, &k1);
+        const int Kr = k1 - k0;
+        if (!plan_cg1_k(s, Kr, &g, &t, &kp)) return 0;
+        if (s->cl.nranks > 1 && (kp < 2 || Kr - (g - 1) * kp < 2)) return 0;
+        if (r < s->cl.rank) base += g;
+        if (r == s->cl.rank) { *groups = g; *threads = t; *kpw = kp; }
+        total += g;
+    }
+    *flat_total = total; *flat_base = base;
+    return 1;
+}
+
 // One rank's part of a PCG solve sharded over the cluster: d_S / d_Pinv / d_gamma / d_lambda are FULL-system arrays
-// (block row 0 first) of which this rank reads / writes the rows of its range only.  Every rank must call it with the
-// same exit_tol and max_iters; the launches synchronise with each other on the device (bounded spins), never on the
-// host.  d_iters: as gato_pcg (-1 = a hand-off timed out).  d_lambda holds this rank's slice on return.
+// (block row 0 first) of which this rank reads / writes the rows of its range only (variant 1: Pinv and gamma also on the
+// neighbouring knots, see cluster_plan_cg1 / gato_cluster_linsys).  Every rank must call it with the same exit_tol and
+// max_iters; the launches synchronise with each other on the device (bounded spins), never on the host.  d_iters: as gato_pcg
+// (-1 = a hand-off timed out).  d_lambda holds this rank's slice on return - and, on every rank but the last, the right
+// neighbour's first block at row k_end (cluster_lambda_ghost: what the dz of this rank's last knot needs).
 extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
                                 double exit_tol, int max_iters, int *d_iters, void *stream)
 {
     if (!s->cl.on) { set_error("cluster_pcg: gato_cluster_connect first"); return GATO_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
-    int groups = 0, threads = 0, kpw = 0;
-    const int fits = cluster_plan(s, &groups, &threads, &kpw);
+    // a captured launch would be REPLAYED with the epochs of the capture: stale granules would pass the polls (see pcg_one)
+    if (stream_is_capturing(st)) {
+        set_error("cluster_pcg: a cluster launch cannot be captured into a graph (its hand-off epochs are launch arguments)");
+        return GATO_EINVAL;
+    }
+    int groups = 0, threads = 0, kpw = 0, cg1_total = 0, cg1_base = 0;
+    const bool cg1 = cluster_plan_cg1(s, &groups, &threads, &kpw, &cg1_total, &cg1_base) != 0;
+    const int fits = cg1 ? 1 : cluster_plan(s, &groups, &threads, &kpw);
     if (!fits) {
         set_error("cluster_pcg: %d knots per rank do not fit a persistent launch on %d CUs", s->cl.k1 - s->cl.k0, s->num_cus);
         return GATO_EINVAL;
@@ -1705,12 +1745,14 @@ extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_P
     a.S_bd = d_S; a.P_bd = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda;
     a.lambda0 = s->true_warm_start ? d_lambda : nullptr;
     a.K = s->d.K; a.max_iters = max_iters; a.exit_tol = exit_tol;
-    a.batch = 1; a.semi = s->plan_semi; a.dpp_rows = s->plan_dpp;
+    a.batch = 1; a.semi = cg1 ? 0 : s->plan_semi; a.dpp_rows = cg1 ? 0 : s->plan_dpp;
     a.wave_pub = s->wave_pub;
     a.knots_per_wg = kpw; a.groups = groups; a.threads = threads;
     a.slots = s->slots; a.iters = d_iters ? d_iters : s->iters; a.status = s->status;
     a.epoch0 = s->pcg_epoch; s->pcg_epoch += need;
     a.xepoch0 = s->cl.xepoch; s->cl.xepoch += need;
+    a.lam_off = s->cl.lam_off;
+    a.lam_tag = a.xepoch0 + need;                   // > every epoch of this launch, < every epoch of the next: unique, never 0
     if (++s->pcg_launch_id <= 0) s->pcg_launch_id = 1;
     a.launch_id = s->pcg_launch_id;
     a.final_eta = s->final_eta;
@@ -1722,7 +1764,11 @@ extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_P
     // flat exchange when the whole cluster has at most 256 workgroups and every rank runs the plain resident variant:
     // every rank derives every rank's geometry from the same rule (same device type, same options on all ranks)
     a.flat = 0;
-    if (s->cluster_flat != 0 && s->cl.nranks > 1 && !a.semi) {
+    if (cg1) {
+        if (s->cluster_flat != 0 && s->cl.nranks > 1 && cg1_total <= 256) {
+            a.flat = 1; a.flat_groups = cg1_total; a.flat_base = cg1_base; a.flat_off = s->cl.flat_off;
+        }
+    } else if (s->cluster_flat != 0 && s->cl.nranks > 1 && !a.semi) {
         int total = 0, base = 0, ok = 1;
         const int k0s = s->cl.k0, k1s = s->cl.k1;
         for (int r = 0; r < s->cl.nranks && ok; ++r) {
@@ -1739,11 +1785,51 @@ extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_P
     s->cl.last_flat = a.flat;
     a.ev_start = s->time_pcg ? s->ev_pcg0 : nullptr;
     a.ev_stop = s->time_pcg ? s->ev_pcg1 : nullptr;
-    s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT; s->last_variant = 0;
+    s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT; s->last_variant = cg1 ? 1 : 0;
     s->last_semi = a.semi; s->last_stream = st;
     // the launches of a cluster wait for EACH OTHER: they are never queued behind one another (ranks sharing a device
     // exist in tests only), but they count for the other launches of this process
     int rc;
-    if ((rc = a.semi == 3 ? s->ops->pcg_dma(a, st) : s->ops->pcg_resident(a, st))) return rc;
+    if ((rc = cg1 ? s->ops->pcg_cg1(a, st) : a.semi == 3 ? s->ops->pcg_dma(a, st) : s->ops->pcg_resident(a, st))) return rc;
     return gate_after(s->device, groups, st);
+}
+
+// One rank's part of a WHOLE solve sharded over the cluster (gato_linsys, gpu_library.cu:25-83, on this rank's knot range): the
+// stage kernels on the knots its PCG shard reads (S / Pinv rows k0..k1-1 complete: S[k].right comes from the Schur step of knot
+// k+1 and the stair blocks need theta^-1 of both neighbours, gamma on k0-1..k1 - hence CSR scatter + inversions on [k0-2-h, k1+1+h),
+// Schur steps on [k0-1-h, k1+1+h), stair on [k0-h, k1+h); h = 1 for the single-reduction recurrence, whose edge workgroups also
+// multiply with the neighbouring knots' Pinv rows), the rank's cluster launch, and dz on [k0, k1) - lambda_{k1} arrives inside
+// the launch (cluster_lambda_ghost), so NOTHING crosses the host or a collective between assembly, PCG and dz: one call, a handful
+// of enqueues.  CSR inputs, d_g, d_c: the full system (replicated); d_lambda / d_dz: full-length arrays of which the rank writes
+// its rows (lambda: + row k1).  Work buffers: the solver's own.
+extern "C" int gato_cluster_linsys(gato_solver *s, const int *d_G_row, const int *d_G_col, const void *d_G_val, const int *d_C_row,
+                                   const int *d_C_col, const void *d_C_val, const void *d_g, const void *d_c, double exit_tol,
+                                   int max_iters, double rho, void *d_lambda, void *d_dz, int *d_iters, void *stream)
+{
+    if (!s->cl.on) { set_error("cluster_linsys: gato_cluster_connect first"); return GATO_EINVAL; }
+    if (s->precon_mode != GATO_PRECON_STAIR) { set_error("cluster_linsys: the stair preconditioner only"); return GATO_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    const int K = s->d.K, k0 = s->cl.k0, k1 = s->cl.k1;
+    const int h = (s->pcg_variant == 1 && !s->true_warm_start) ? 1 : 0;           // wide enough for either recurrence the launch may take
+    auto clip = [&](int k) { return k < 0 ? 0 : (k > K ? K : k); };
+    auto range = [&](int lo, int hi) { s->d.k_lo = clip(lo); s->d.k_hi = clip(hi); if (s->d.k_hi == 0) s->d.k_lo = 0; };
+    int rc;
+    const bool ts = s->time_stages != 0;
+    if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[0], st));
+    range(k0 - 2 - h, k1 + 1 + h);
+    rc = s->ops->convert(s->d, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, rho, s->G_dense, s->C_dense, nullptr, st);
+    // (form_schur inverts the Q_k, R_k of its knot range first and then runs the Schur steps on the same range: the step of the
+    //  range's first knot reads an inverse outside the range and only writes rows k0-2-h of S / Pinv, which nobody reads)
+    if (!rc) rc = s->ops->form_schur(s->d, s->G_dense, s->C_dense, d_g, d_c, s->Sbd, s->Pbd, s->gamma, s->Ginv, false, st);
+    if (!rc) { range(k0 - h, k1 + h); rc = s->ops->form_ss(s->d, s->Sbd, s->Pbd, st); }
+    s->d.k_lo = s->d.k_hi = 0;
+    if (rc) return rc;
+    if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[1], st));
+    if ((rc = gato_cluster_pcg(s, s->Sbd, s->Pbd, s->gamma, d_lambda, exit_tol, max_iters, d_iters, stream))) return rc;
+    if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[2], st));
+    s->d.k_lo = k0; s->d.k_hi = k1;
+    rc = s->ops->compute_dz(s->d, s->Ginv, s->C_dense, d_g, d_lambda, d_dz, st);
+    s->d.k_lo = s->d.k_hi = 0;
+    if (ts && !rc) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[3], st));
+    return rc;
 }

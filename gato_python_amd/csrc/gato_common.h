@@ -195,6 +195,12 @@ struct PcgLaunch {
     int flat, flat_groups, flat_base;
     size_t flat_off;             // granules from the start of a mirror to its flat area
     unsigned xepoch0;            // cross-GPU epochs: in lock-step on all ranks (only cluster launches draw from this counter)
+    // cluster launches, at exit: the rank's first lambda block goes into the LEFT neighbour's mirror (granules at lam_off, tag
+    // lam_tag: unique per launch, the same on every rank) and the rank's last workgroup stores the right neighbour's block at
+    // lambda[k_end] - dz of the rank's last knot needs lambda_{k_end} (gato_schur.cuh:833-838), so no lambda all-reduce stands
+    // between the PCG and the dz launch of a sharded solve.  lam_tag = 0: off.
+    size_t lam_off;
+    unsigned lam_tag;
     int launch_id;               // > 0; a timed-out hand-off stores it into *status (stale ids of earlier launches are ignored)
     int *iters;                  // device
     int *status;                 // device, 0 ok / 1 timeout
@@ -207,14 +213,14 @@ struct PcgLaunch {
     int diag;                          // 2: the build with the timing-only switches (ablate) but no stamps
     int mixed_dense;                   // fp64 one-workgroup mixed-rows kernel: round 2's dense one-row waves instead of DPP rows (A/B)
     int coop;                          // multi-workgroup persistent launches through hipLaunchCooperativeKernel (option coop_launch)
-    int pipelined;                     // launch_pcg_cg1: the pipelined recurrence (pcg_variant = 2) instead of the single-reduction one
     int f32_hybrid;                    // fp32 one-workgroup kernel: the hybrid of two-row and DPP-row waves (opt-in: measured equal)
 };
 
 // Cross-GPU mirror of a cluster launch, per epoch parity (granules): one 128-B line per rank for its total (written by
 // that rank's workgroup 0 into EVERY rank's mirror), then the left and the right ghost S-block (written by the
 // neighbouring rank's last / first workgroup).  Every line has exactly one writer.
-__host__ __device__ inline int pcg_xghost_granules(int S, int esz) { return ((S * (esz / 4) + 15) / 16) * 16; }
+// (two S-blocks per side: the single-reduction recurrence exchanges the first / last TWO blocks of w, gato_pcg_cg1.hip)
+__host__ __device__ inline int pcg_xghost_granules(int S, int esz) { return ((2 * S * (esz / 4) + 15) / 16) * 16; }
 __host__ __device__ inline int pcg_xslot_granules(int S, int esz) { return 16 * GATO_MAX_RANKS + 2 * pcg_xghost_granules(S, esz); }
 
 // Granules (8 B: {epoch:32 | payload:32}) per workgroup and parity in the hand-off area.
@@ -232,6 +238,15 @@ __host__ __device__ inline int pcg_slot_granules_cg1(int S, int esz)
     int gpv = esz / 4;
     return 16 + ((4 * S * gpv + 15) / 16) * 16;
 }
+
+// A workgroup's slot in the FLAT area of a cluster mirror: room for either recurrence's slot.
+__host__ __device__ inline int pcg_flat_slot_granules(int S, int esz)
+{
+    const int a = pcg_slot_granules(S, esz), b = pcg_slot_granules_cg1(S, esz);
+    return a > b ? a : b;
+}
+// Granules of the lambda ghost block behind the flat area (one S-block, whole 128-B lines).
+__host__ __device__ inline int pcg_lamghost_granules(int S, int esz) { return ((S * (esz / 4) + 15) / 16) * 16; }
 
 struct PcgPlan {
     int max_threads;     // launch bound of the instantiation

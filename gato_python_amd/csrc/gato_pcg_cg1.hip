@@ -21,10 +21,20 @@
 namespace gato {
 namespace {
 
-template <typename T, int S, int MAXT>
+// MR: one rank of a cluster launch (gato_cluster_pcg with pcg_variant = 1): the knots are sharded over the GPUs of
+// a node and the ONE exchange of an iteration crosses them - where an exchange costs most.  Both forms of pcg_resident_kernel<...,
+// MR>: FLAT (a.flat: every workgroup of every rank has a slot in every mirror; its two partial dots go into all mirrors, its
+// first / last two blocks of w into its own GPU's mirror and, at the rank's edges, the neighbouring GPU's; polls on the own mirror)
+// and TWO LEVELS (level 1 = the hand-off below inside the GPU; then workgroup 0 stores the rank's two totals into every mirror, the
+// rank's first / last workgroup their two edge blocks into the neighbour's mirror).  Sums in slot / rank order: identical on
+// every workgroup of every rank, so every rank takes the same exit decision.  The ghost-lane knots k0 - 1 and k1 of a rank's
+// edge workgroups belong to the neighbouring rank: their Pinv rows (and gamma two knots deep) are read from the full-system
+// arrays, so a sharded assembly must cover one knot more on either side than for the default recurrence (gato_cluster_linsys).
+template <typename T, int S, int MAXT, bool MR = false>
 __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
 {
     typedef Granule<T> Gr;
+    typedef GranuleSys<T> XGr;
     constexpr int GPV = Gr::GPV;
     constexpr int VW = VecOf<T>::W;
     constexpr int SP = pad_to(S, VW);
@@ -49,13 +59,19 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
     if (X > 0 && wg >= W) return;
     const size_t sys = batched ? blockIdx.x : 0;
     const int K = a.K;
-    const int k0 = wg * a.knots_per_wg;
-    const int nk = min(a.knots_per_wg, K - k0);
+    const int k_begin = MR ? a.k_begin : 0, k_end = MR ? a.k_end : K;       // this launch's knot range (a rank's shard)
+    const int R = MR ? a.nranks : 1;
+    const int k0 = k_begin + wg * a.knots_per_wg;
+    const int nk = min(a.knots_per_wg, k_end - k0);
     const int k1 = k0 + nk;
     const int jl = tid / S, r_ = tid - jl * S;        // lane knot slot (0 = knot k0-1), row
     const int k = k0 - 1 + jl;
     const bool lane_on = jl < nk + 2 && k >= 0 && k < K;     // own or ghost-lane knot
     const bool own = lane_on && k >= k0 && k < k1;
+    // a neighbouring block row exists in the SYSTEM (k0 > 0, k1 < K) and belongs to a workgroup of this launch or (MR) to the
+    // neighbouring rank
+    const bool loc_left = MR ? wg > 0 : k0 > 0, loc_right = MR ? wg < W - 1 : k1 < K;
+    const bool x_left = MR && wg == 0 && k0 > 0, x_right = MR && wg == W - 1 && k1 < K;
 
     const T *__restrict__ dS = static_cast<const T *>(a.S_bd) + sys * 3 * S * S * K;
     const T *__restrict__ dP = static_cast<const T *>(a.P_bd) + sys * 3 * S * S * K;
@@ -75,6 +91,17 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
     const int slotG = pcg_slot_granules_cg1(S, (int)sizeof(T));
     gu64 *slots = (gu64 *)a.slots;
     gi32 *g_status = (gi32 *)a.status;
+    // cross-GPU mirrors (MR): layout as in pcg_resident_kernel, two ghost blocks per side
+    const int xslotG = pcg_xslot_granules(S, (int)sizeof(T));
+    const int xghL = 16 * GATO_MAX_RANKS, xghR = xghL + pcg_xghost_granules(S, (int)sizeof(T));
+    unsigned xepoch = MR ? a.xepoch0 : 0u;
+    gu64 *xp_prev = nullptr, *xp_next = nullptr;
+    __shared__ unsigned long long s_xpeer[MR ? GATO_MAX_RANKS : 1];
+    if constexpr (MR) {
+        if (a.rank > 0) xp_prev = (gu64 *)a.xpeer[a.rank - 1];
+        if (a.rank < R - 1) xp_next = (gu64 *)a.xpeer[a.rank + 1];
+        if (wave == 0 && lane < R) s_xpeer[lane] = (unsigned long long)a.xpeer[lane];
+    }
     if (tid == 0) s_abort = 0;
     // r = gamma on knots k0-2 .. k1+1 (zeros outside the system)
     for (int i = tid; i < (nk + 4) * S; i += blockDim.x) {
@@ -99,7 +126,124 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
     const unsigned long long t_limit = a.timeout_ticks;
 
     // one hand-off: two dots + the neighbours' two boundary blocks of w on each side
+    // ---- MR, flat form: one level across the node (see the header of this kernel and pcg_resident_kernel's allreduce_flat)
+    auto exchange_flat = [&](T d0, T d1, T &t0, T &t1) {
+        if constexpr (MR) {
+            ++epoch; ++xepoch;
+            partials_store(wpart[xepoch & 1][0], wave, lane, d0);
+            partials_store(wpart[xepoch & 1][1], wave, lane, d1);
+            const int WT = a.flat_groups, gwi = a.flat_base + wg;
+            const size_t so = a.flat_off + ((size_t)(xepoch & 1) * WT + gwi) * slotG;      // this workgroup's slot in a mirror
+            gu64 *fl = (gu64 *)a.xslots;
+            if (own) {
+                const int j = k - k0;
+                if (j < 2) {
+                    XGr::store(fl + so + 16 + (j * S + r_) * GPV, xepoch, w);
+                    if (x_left) XGr::store(xp_prev + so + 16 + (j * S + r_) * GPV, xepoch, w);
+                }
+                if (j >= nk - 2) {
+                    XGr::store(fl + so + 16 + ((2 + j - (nk - 2)) * S + r_) * GPV, xepoch, w);
+                    if (x_right) XGr::store(xp_next + so + 16 + ((2 + j - (nk - 2)) * S + r_) * GPV, xepoch, w);
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                T s0 = partials_total(wpart[xepoch & 1][0], nwaves, lane);
+                T s1 = partials_total(wpart[xepoch & 1][1], nwaves, lane);
+                if (lane < R) {                                                    // the two partial dots go into EVERY mirror
+                    XGr::store((gu64 *)s_xpeer[lane] + so, xepoch, s0);
+                    XGr::store((gu64 *)s_xpeer[lane] + so + GPV, xepoch, s1);
+                }
+                gu64 *pbase = fl + a.flat_off + (size_t)(xepoch & 1) * WT * slotG;
+                const bool left = lane < 32;
+                const bool have_nb = left ? (k0 > 0) : (k1 < K);
+                const int nb = left ? gwi - 1 : gwi + 1;
+                const int he = lane & 31;
+                gu64 *hp[2];
+                bool hw[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = he + 32 * q;
+                    hw[q] = have_nb && e < 2 * S;
+                    hp[q] = hw[q] ? pbase + (size_t)nb * slotG + 16 + ((left ? 2 * S : 0) + e) * GPV : pbase + (size_t)gwi * slotG;
+                }
+                gu64 *pptr[PM];
+#pragma unroll
+                for (int m = 0; m < PM; ++m) pptr[m] = pbase + (size_t)min(lane + 64 * m, WT - 1) * slotG;
+                const int pm_count = (WT + 63) >> 6;
+                unsigned long long raw[PM][2 * GPV], hraw[2][GPV];
+                if (WT > 32) {
+                    const int sl = 10 + WT / 22;
+                    for (int i = 0; i < sl; ++i) __builtin_amdgcn_s_sleep(1);
+                }
+                const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
+                bool fail = false;
+                for (unsigned spin = 0;; ++spin) {
+#pragma unroll
+                    for (int m = 0; m < PM; ++m)
+                        if (m < pm_count) {
+#pragma unroll
+                            for (int g = 0; g < 2 * GPV; ++g)
+                                raw[m][g] = __hip_atomic_load(pptr[m] + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int g = 0; g < GPV; ++g)
+                            hraw[q][g] = __hip_atomic_load(hp[q] + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    bool ok = true;
+#pragma unroll
+                    for (int m = 0; m < PM; ++m)
+                        if (m < pm_count) {
+#pragma unroll
+                            for (int g = 0; g < 2 * GPV; ++g) ok &= (unsigned)(raw[m][g] >> 32) == xepoch;
+                        }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int g = 0; g < GPV; ++g) ok &= (unsigned)(hraw[q][g] >> 32) == xepoch;     // own partial line: current
+                    if (__all(ok)) break;
+                    if ((spin & 255u) == 255u) {
+                        const bool late = __builtin_amdgcn_s_memrealtime() - tstart > t_limit;
+                        const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
+                        if (late || other) { fail = true; break; }
+                    }
+                }
+                if (fail && lane == 0) {
+                    __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_abort = 1;
+                }
+                T a0 = (T)0, a1 = (T)0;
+#pragma unroll
+                for (int m = 0; m < PM; ++m)
+                    if (m < pm_count && lane + 64 * m < WT) {
+                        unsigned long long x0[GPV], x1[GPV];
+#pragma unroll
+                        for (int g = 0; g < GPV; ++g) { x0[g] = raw[m][g]; x1[g] = raw[m][GPV + g]; }
+                        a0 += XGr::decode(x0);
+                        a1 += XGr::decode(x1);
+                    }
+                s0 = wave_sum(a0);
+                s1 = wave_sum(a1);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = he + 32 * q;
+                    if (e < 2 * S) gw[(left ? 0 : 2) + e / S][e % S] = hw[q] ? XGr::decode(hraw[q]) : (T)0;
+                }
+                if (lane == 0) { bc[xepoch & 1][0] = s0; bc[xepoch & 1][1] = s1; }
+            }
+            __syncthreads();
+            t0 = bc[xepoch & 1][0];
+            t1 = bc[xepoch & 1][1];
+            aborted = s_abort != 0;
+        }
+    };
+    const bool flat = MR && a.flat != 0;
     auto exchange = [&](T d0, T d1, T &t0, T &t1) {
+        if constexpr (MR) {
+            if (flat) { exchange_flat(d0, d1, t0, t1); return; }
+            ++xepoch;
+        }
         ++epoch;
         partials_store(wpart[epoch & 1][0], wave, lane, d0);
         partials_store(wpart[epoch & 1][1], wave, lane, d1);
@@ -109,8 +253,16 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
             if (j < 2) Gr::store(mine + 16 + (j * S + r_) * GPV, epoch, w);                  // first two blocks
             if (j >= nk - 2) Gr::store(mine + 16 + ((2 + j - (nk - 2)) * S + r_) * GPV, epoch, w);   // last two
         }
+        if constexpr (MR) {                 // the rank's two edge blocks go straight into the neighbouring GPU's mirror
+            if (own) {
+                const int j = k - k0;
+                const size_t xo = (size_t)(xepoch & 1) * xslotG;
+                if (x_left && j < 2) XGr::store(xp_prev + xo + xghR + (j * S + r_) * GPV, xepoch, w);
+                if (x_right && j >= nk - 2) XGr::store(xp_next + xo + xghL + ((j - (nk - 2)) * S + r_) * GPV, xepoch, w);
+            }
+        }
         __syncthreads();
-        if (W == 1) {
+        if (W == 1 && !(MR && R > 1)) {
             t0 = partials_total(wpart[epoch & 1][0], nwaves, lane);
             t1 = partials_total(wpart[epoch & 1][1], nwaves, lane);
             return;
@@ -118,14 +270,22 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
         if (wave == 0) {
             T s0 = partials_total(wpart[epoch & 1][0], nwaves, lane);
             T s1 = partials_total(wpart[epoch & 1][1], nwaves, lane);
+            bool fail = false;
+            const bool left = lane < 32;
+            const int he = lane & 31;
+            if (W == 1) {                  // (cluster launch with one workgroup on this GPU: the ghosts come from level 2 only)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = he + 32 * q;
+                    if (e < 2 * S) gw[(left ? 0 : 2) + e / S][e % S] = (T)0;
+                }
+            } else {
             if (lane == 0) { Gr::store(mine, epoch, s0); Gr::store(mine + GPV, epoch, s1); }
             gu64 *pbase = slots + (size_t)(epoch & 1) * W * slotG;
             // halo: lanes [0,32) fetch from the left neighbour (its last two blocks), [32,64) from the right one
             // (its first two); each lane covers elements e, e+32 of the 2S-element pair of blocks.
-            const bool left = lane < 32;
-            const bool have_nb = left ? (k0 > 0) : (k1 < K);
+            const bool have_nb = left ? loc_left : loc_right;
             const int nb = left ? wg - 1 : wg + 1;
-            const int he = lane & 31;
             gu64 *hp[2];
             bool hw[2];
 #pragma unroll
@@ -140,7 +300,6 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
             const int pm_count = (W + 63) >> 6;
             unsigned long long raw[PM][2 * GPV], hraw[2][GPV];
             const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
-            bool fail = false;
             // sleep before the first sweep of a cross-XCD hand-off (round 1: s_sleep 10, -6..-17 % here): with 512-thread workgroups
             // the W-dependent rule of gato_pcg_resident.hip (l_sleep; 14/7/4096 f32 2.87 -> 2.72 us); with 256-thread workgroups
             // (32/16, fp64) that rule overshoots (32/16/1024 f32 3.06 -> 3.25): they keep the old value
@@ -181,10 +340,6 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
                     if (late || other) { fail = true; break; }
                 }
             }
-            if (fail && lane == 0) {
-                __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_abort = 1;
-            }
             T a0 = (T)0, a1 = (T)0;
 #pragma unroll
             for (int m = 0; m < PM; ++m)
@@ -201,6 +356,65 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
             for (int q = 0; q < 2; ++q) {
                 const int e = he + 32 * q;
                 if (e < 2 * S) gw[(left ? 0 : 2) + e / S][e % S] = hw[q] ? Gr::decode(hraw[q]) : (T)0;
+            }
+            }
+            if constexpr (MR) {
+                if (R > 1 && !fail) {
+                    // ---- level 2, across the GPUs: s0, s1 = this rank's totals (identical in all its workgroups)
+                    const size_t xo = (size_t)(xepoch & 1) * xslotG;
+                    if (wg == 0 && lane < R) {
+                        XGr::store((gu64 *)s_xpeer[lane] + xo + a.rank * 16, xepoch, s0);
+                        XGr::store((gu64 *)s_xpeer[lane] + xo + a.rank * 16 + GPV, xepoch, s1);
+                    }
+                    gu64 *xl = (gu64 *)a.xslots + xo;                         // polls stay on THIS GPU's memory
+                    gu64 *tptr = xl + (size_t)min(lane, R - 1) * 16;
+                    const bool xside = left ? x_left : x_right;
+                    gu64 *xh[2];
+                    bool xw_[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int e = he + 32 * q;
+                        xw_[q] = xside && e < 2 * S;
+                        xh[q] = xw_[q] ? xl + (left ? xghL : xghR) + e * GPV : tptr;
+                    }
+                    unsigned long long traw[2 * GPV], xraw[2][GPV];
+                    const unsigned long long t0x = __builtin_amdgcn_s_memrealtime();
+                    for (unsigned spin = 0;; ++spin) {
+#pragma unroll
+                        for (int g = 0; g < 2 * GPV; ++g) traw[g] = __hip_atomic_load(tptr + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int g = 0; g < GPV; ++g) xraw[q][g] = __hip_atomic_load(xh[q] + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        bool ok = true;
+#pragma unroll
+                        for (int g = 0; g < 2 * GPV; ++g) ok &= (unsigned)(traw[g] >> 32) == xepoch;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int g = 0; g < GPV; ++g) ok &= (unsigned)(xraw[q][g] >> 32) == xepoch;
+                        if (__all(ok)) break;
+                        if ((spin & 255u) == 255u) {
+                            const bool late = __builtin_amdgcn_s_memrealtime() - t0x > t_limit;
+                            const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
+                            if (late || other) { fail = true; break; }
+                        }
+                    }
+                    unsigned long long y0[GPV], y1[GPV];
+#pragma unroll
+                    for (int g = 0; g < GPV; ++g) { y0[g] = traw[g]; y1[g] = traw[GPV + g]; }
+                    s0 = partials_sum(lane < R ? XGr::decode(y0) : (T)0);        // rank order, the same tree on every GPU
+                    s1 = partials_sum(lane < R ? XGr::decode(y1) : (T)0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int e = he + 32 * q;
+                        if (xw_[q]) gw[(left ? 0 : 2) + e / S][e % S] = XGr::decode(xraw[q]);
+                    }
+                }
+            }
+            if (fail && lane == 0) {
+                __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_abort = 1;
             }
             if (lane == 0) { bc[epoch & 1][0] = s0; bc[epoch & 1][1] = s1; }
         }
@@ -234,7 +448,7 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
             lam += alpha * p;
             r -= alpha * s;
             if (own) xr[(jl + 1) * SP + r_] = r;
-            if (W > 1 && ghost_thr) {
+            if ((W > 1 || (MR && R > 1)) && ghost_thr) {
                 g_s = gw[gb][ge] + beta * g_s;
                 g_r -= alpha * g_s;
                 if (ghost_on) xr[gslot * SP + ge] = g_r;
@@ -250,304 +464,17 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
         }
     }
     if (own) dL[(size_t)k * S + r_] = lam;
+    if constexpr (MR) (void)cluster_lambda_ghost<T, S>(a, wg, W, dL, aborted);      // lambda_{k_end} for this rank's dz launch
     if (wg == 0 && tid == 0) {
         a.iters[sys] = aborted ? -1 : iters;
         if (a.final_eta && sys == 0) *a.final_eta = (double)gamma_new;
     }
 }
 
-// ---- Pipelined PCG (Ghysels-Vanroose), OPT-IN variant 2 (solver option pcg_variant = 2) ---------------------------------
-// hide the hand-off instead of shortening it.  The single-reduction kernel above still WAITS for its one
-// all-to-all per iteration (95 % of the wave-cycles of a 114-workgroup launch are waits).  Here the two dots of an iteration
-// are published BEFORE its two block-tridiagonal products and collected after them:
-//
-//     r, u = Pinv r, w = S u                                      (set-up, one blocking exchange of w's boundary blocks)
-//     loop:  gamma = r.u, delta = w.u          -> published (granules), nobody waits
-//            m = Pinv w ;  n = S m             <- the all-to-all travels while these run
-//            n's boundary blocks               -> published (the neighbours need them for their ghost blocks)
-//            collect gamma, delta, the neighbours' blocks of n
-//            exit test on |gamma| (= the reference's eta' = r.Pinv r, gato_pcg.cuh:404)
-//            beta = gamma / gamma_old ;  alpha = gamma / (delta - beta gamma / alpha_old)
-//            z = n + beta z ; q = m + beta q ; s = w + beta s ; p = u + beta p
-//            lambda += alpha p ; r -= alpha s ; u -= alpha q ; w -= alpha z
-//
-// Same Krylov iterates as the reference recurrence in exact arithmetic; in floating point u, w (and s, q, z) are carried by
-// recurrences instead of products, so rounding differs more than in the single-reduction variant and the attainable accuracy
-// is lower (the usual price of pipelined CG): opt-in only, parity is claimed for the default recurrence.  Layout as above:
-// a workgroup also computes m on its two neighbouring knots (ghost lanes keep those Pinv rows), which takes w two knots deep
-// on each side; those four ghost blocks of w are advanced locally (ghost_z = ghost_n + beta ghost_z, ghost_w -= alpha ghost_z)
-// from the neighbours' first / last two blocks of n - the only vector data in the hand-off.  One neighbour-to-neighbour
-// latency stays on the critical path (the blocks of n), the W x W sweep does not.
-// MEASURED (round 4): 14/7/4096 f32 2.78 us per iteration against 2.70 single-reduction and 3.48 default; 14/7/512 2.53 /
-// 2.36 / 2.20; 32/16/1024 3.99 / 3.26 / 3.58; 14/7/4096 f64 4.16 / 5.19 / 4.13 - NO gain over the single-reduction variant:
-// on this chip a sweep of W granule lines and a sweep of the two neighbours' lines cost the same (store -> visible 0.5 us +
-// sc1 load 0.8 us across XCDs: latency, not bandwidth), and the neighbours' blocks of n cannot be published before the
-// products that form them, so exactly one exchange latency stays exposed either way.  Hiding that one too needs ghost zones
-// that grow by two knots per iteration (s-step methods), not a reordering.  Kept as an option: correct, deterministic,
-// tested against its own restatement (oracle.pcg_pipelined).
-#ifndef GATO_PIPE_SLEEP
-#define GATO_PIPE_SLEEP 12
-#endif
-template <typename T, int S, int MAXT>
-__global__ __launch_bounds__(MAXT) void pcg_pipe_kernel(PcgLaunch a)
-{
-    typedef Granule<T> Gr;
-    constexpr int GPV = Gr::GPV;
-    constexpr int VW = VecOf<T>::W;
-    constexpr int SP = pad_to(S, VW);
-    constexpr int MAXK = (MAXT + S - 1) / S;          // knots covered by lanes (own + 2 ghost-lane knots)
-    constexpr int PM = 256 / 64;
-    __shared__ __attribute__((aligned(16))) T xw[(MAXK + 4) * SP];   // w (r during set-up) on knots k0-2 .. k1+1   (slot = k - (k0-2))
-    __shared__ __attribute__((aligned(16))) T xm[(MAXK + 2) * SP];   // m (u during set-up) on knots k0-1 .. k1     (slot = k - (k0-1))
-    __shared__ __attribute__((aligned(32))) T wpart[2][2][4 * ((MAXT + 63) / 64)];
-    __shared__ T gw[4][32];                                          // received blocks: L2, L1, R1, R2
-    __shared__ T bc[2][2];
-    __shared__ int s_abort;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const bool batched = a.batch > 1;
-    const int X = a.xcd_pack;
-    const int xres = X > 0 ? (int)((blockIdx.x - (unsigned)a.xcd_sel) & 7) : 0;
-    if (X > 0 && xres >= X) return;
-    const int per_x = X > 0 ? (int)(gridDim.x >> 3) : 0;
-    const int wg = batched ? 0 : (X > 0 ? xres * per_x + (int)(blockIdx.x >> 3) : (int)blockIdx.x);
-    const int W = batched ? 1 : (X > 0 ? a.groups : (int)gridDim.x);
-    if (X > 0 && wg >= W) return;
-    const size_t sys = batched ? blockIdx.x : 0;
-    const int K = a.K;
-    const int k0 = wg * a.knots_per_wg;
-    const int nk = min(a.knots_per_wg, K - k0);
-    const int k1 = k0 + nk;
-    const int jl = tid / S, r_ = tid - jl * S;        // lane knot slot (0 = knot k0-1), row
-    const int k = k0 - 1 + jl;
-    const bool lane_on = jl < nk + 2 && k >= 0 && k < K;     // own or ghost-lane knot
-    const bool own = lane_on && k >= k0 && k < k1;
-
-    const T *__restrict__ dS = static_cast<const T *>(a.S_bd) + sys * 3 * S * S * K;
-    const T *__restrict__ dP = static_cast<const T *>(a.P_bd) + sys * 3 * S * S * K;
-    const T *__restrict__ dG = static_cast<const T *>(a.gamma) + sys * S * K;
-    T *__restrict__ dL = static_cast<T *>(a.lambda) + sys * S * K;
-
-    T sm[3 * S], pm[3 * S];
-    {
-        const size_t base = (size_t)(lane_on ? k : 0) * 3 * S * S + r_;
-#pragma unroll
-        for (int c = 0; c < 3 * S; ++c) {
-            const bool ok = lane_on && !(k == 0 && c < S) && !(k == K - 1 && c >= 2 * S);   // gato_utils.cuh:157-174
-            sm[c] = (ok && own) ? dS[base + (size_t)c * S] : (T)0;
-            pm[c] = ok ? dP[base + (size_t)c * S] : (T)0;
-        }
-    }
-    const int slotG = pcg_slot_granules_cg1(S, (int)sizeof(T));
-    gu64 *slots = (gu64 *)a.slots;
-    gi32 *g_status = (gi32 *)a.status;
-    if (tid == 0) s_abort = 0;
-    for (int i = tid; i < (nk + 4) * S; i += blockDim.x) {          // r = gamma on knots k0-2 .. k1+1 (zeros outside the system)
-        const int kk = k0 - 2 + i / S;
-        xw[(i / S) * SP + i % S] = (kk >= 0 && kk < K) ? dG[(size_t)kk * S + i % S] : (T)0;
-    }
-    for (int i = tid; i < (MAXK + 2) * SP; i += blockDim.x) xm[i] = (T)0;
-    __syncthreads();
-
-    // ghost threads: thread t < 4S owns element t%S of ghost block t/S (0: k0-2, 1: k0-1, 2: k1, 3: k1+1)
-    const int gb = tid / S, ge = tid - gb * S;
-    const bool ghost_thr = tid < 4 * S;
-    const int gk = gb < 2 ? k0 - 2 + gb : k1 + (gb - 2);
-    const bool ghost_on = ghost_thr && gk >= 0 && gk < K;
-    const int gslot = gb < 2 ? gb : nk + gb;                       // slot in xw
-    T g_w = (T)0, g_z = (T)0;
-
-    unsigned epoch = a.epoch0;
-    bool aborted = false;
-    const unsigned long long t_limit = a.timeout_ticks;
-    gu64 *mine = nullptr;
-
-    // the workgroup's two partial dots of this epoch -> its slot (wave 0, after the barrier that follows partials_store)
-    auto publish_dots = [&]() {
-        if (W > 1 && wave == 0) {
-            const T s0 = partials_total(wpart[epoch & 1][0], nwaves, lane);
-            const T s1 = partials_total(wpart[epoch & 1][1], nwaves, lane);
-            if (lane == 0) { Gr::store(mine, epoch, s0); Gr::store(mine + GPV, epoch, s1); }
-        }
-    };
-    // the first two and the last two own blocks of a vector -> the slot (the neighbours' ghost blocks)
-    auto publish_blocks = [&](T v) {
-        if (W > 1 && own) {
-            const int j = k - k0;
-            if (j < 2) Gr::store(mine + 16 + (j * S + r_) * GPV, epoch, v);
-            if (j >= nk - 2) Gr::store(mine + 16 + ((2 + j - (nk - 2)) * S + r_) * GPV, epoch, v);
-        }
-    };
-    // wait for every workgroup's dots (if with_dots) and the neighbours' blocks of this epoch; totals -> t0, t1, blocks -> gw
-    auto collect = [&](bool with_dots, T &t0, T &t1) {
-        if (W == 1) {
-            if (with_dots) {
-                t0 = partials_total(wpart[epoch & 1][0], nwaves, lane);
-                t1 = partials_total(wpart[epoch & 1][1], nwaves, lane);
-            }
-            return;
-        }
-        if (wave == 0) {
-            gu64 *pbase = slots + (size_t)(epoch & 1) * W * slotG;
-            const bool left = lane < 32;
-            const bool have_nb = left ? (k0 > 0) : (k1 < K);
-            const int nb = left ? wg - 1 : wg + 1;
-            const int he = lane & 31;
-            gu64 *hp[2];
-            bool hw[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int e = he + 32 * q;
-                hw[q] = have_nb && e < 2 * S;
-                hp[q] = hw[q] ? pbase + (size_t)nb * slotG + 16 + ((left ? 2 * S : 0) + e) * GPV : nullptr;
-            }
-            gu64 *pptr[PM];
-#pragma unroll
-            for (int m = 0; m < PM; ++m) pptr[m] = pbase + (size_t)min(lane + 64 * m, W - 1) * slotG;
-            const int pm_count = with_dots ? (W + 63) >> 6 : 0;
-            unsigned long long raw[PM][2 * GPV], hraw[2][GPV];
-            const unsigned long long tstart = __builtin_amdgcn_s_memrealtime();
-            bool fail = false;
-            // the neighbours' blocks were stored a moment ago: a first sweep that comes too early costs a whole extra round trip
-            // across XCDs (the rule of the other kernels; option ablate bits 8..15 override the units for tuning)
-            if (W > 32 && with_dots) {
-                // measured (tools: tune_pcg.run with ablate = (units + 1) << 8): 14/7/4096 f32 0: 2.89, 8: 2.82, 12: 2.78, 16: 2.86 us per
-                // iteration; 256-thread workgroups (fp64, S = 32) 0: 4.16 / 4.09, 8: 4.36 / 3.99, 12: 4.46 / 4.01
-                const int sl = (a.ablate >> 8) & 255 ? ((a.ablate >> 8) & 255) - 1 : (blockDim.x >= 512 ? GATO_PIPE_SLEEP : GATO_PIPE_SLEEP / 3);
-                for (int i = 0; i < sl; ++i) __builtin_amdgcn_s_sleep(1);
-            }
-            for (unsigned spin = 0;; ++spin) {
-#pragma unroll
-                for (int m = 0; m < PM; ++m)
-                    if (m < pm_count) {
-#pragma unroll
-                        for (int g = 0; g < 2 * GPV; ++g)
-                            raw[m][g] = __hip_atomic_load(pptr[m] + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int g = 0; g < GPV; ++g)
-                        hraw[q][g] = hw[q] ? __hip_atomic_load(hp[q] + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)epoch << 32);
-                bool ok = true;
-#pragma unroll
-                for (int m = 0; m < PM; ++m)
-                    if (m < pm_count) {
-#pragma unroll
-                        for (int g = 0; g < 2 * GPV; ++g) ok &= (unsigned)(raw[m][g] >> 32) == epoch;
-                    }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int g = 0; g < GPV; ++g) ok &= (unsigned)(hraw[q][g] >> 32) == epoch;
-                if (__all(ok)) break;
-                if ((spin & 255u) == 255u) {
-                    const bool late = __builtin_amdgcn_s_memrealtime() - tstart > t_limit;
-                    const bool other = __hip_atomic_load(g_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
-                    if (late || other) { fail = true; break; }
-                }
-            }
-            if (fail && lane == 0) {
-                __hip_atomic_store(g_status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_abort = 1;
-            }
-            if (with_dots) {
-                T a0 = (T)0, a1 = (T)0;
-#pragma unroll
-                for (int m = 0; m < PM; ++m)
-                    if (m < pm_count && lane + 64 * m < W) {
-                        unsigned long long x0[GPV], x1[GPV];
-#pragma unroll
-                        for (int g = 0; g < GPV; ++g) { x0[g] = raw[m][g]; x1[g] = raw[m][GPV + g]; }
-                        a0 += Gr::decode(x0);
-                        a1 += Gr::decode(x1);
-                    }
-                const T s0 = wave_sum(a0), s1 = wave_sum(a1);
-                if (lane == 0) { bc[epoch & 1][0] = s0; bc[epoch & 1][1] = s1; }
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int e = he + 32 * q;
-                if (e < 2 * S) gw[(left ? 0 : 2) + e / S][e % S] = hw[q] ? Gr::decode(hraw[q]) : (T)0;
-            }
-        }
-        __syncthreads();
-        if (with_dots) { t0 = bc[epoch & 1][0]; t1 = bc[epoch & 1][1]; }
-        aborted = s_abort != 0;
-    };
-
-    // set-up: u = Pinv r (own + ghost-lane knots), w = S u (own), then the neighbours' boundary blocks of w (blocking)
-    T lam = (T)0, r = own ? xw[(jl + 1) * SP + r_] : (T)0;
-    T u = lane_on ? row_times_window<T, S, SP>(pm, &xw[jl * SP]) : (T)0;      // window slots jl, jl+1, jl+2 = knots k-1..k+1
-    if (lane_on) xm[jl * SP + r_] = u;
-    __syncthreads();
-    T w = own ? row_times_window<T, S, SP>(sm, &xm[(jl - 1) * SP]) : (T)0;    // xm slot = k - (k0-1) = jl
-    if (!own) u = (T)0;
-    ++epoch;
-    mine = slots + ((size_t)(epoch & 1) * W + wg) * slotG;
-    publish_blocks(w);
-    __syncthreads();                                                            // every lane has read xw (r) and xm (u)
-    {
-        T d0, d1;
-        collect(false, d0, d1);
-    }
-    if (ghost_thr) g_w = W > 1 ? gw[gb][ge] : (T)0;
-    if (own) xw[(jl + 1) * SP + r_] = w;
-    if (ghost_thr && gslot < nk + 4) xw[gslot * SP + ge] = ghost_on ? g_w : (T)0;
-    partials_store(wpart[(epoch + 1) & 1][0], wave, lane, own ? r * u : (T)0);           // the first iteration's dots
-    partials_store(wpart[(epoch + 1) & 1][1], wave, lane, own ? w * u : (T)0);
-    __syncthreads();
-
-    T p = (T)0, s = (T)0, q = (T)0, z = (T)0;
-    T gamma_ = (T)0, gamma_old = (T)0, delta = (T)0, alpha = (T)0, beta = (T)0;
-    const bool rec = a.eta_hist && wg == 0 && tid == 0 && sys == 0;
-    int iters = a.max_iters;
-    const T tol = (T)a.exit_tol;
-    for (int it = 0; !aborted && it <= a.max_iters; ++it) {
-        ++epoch;
-        mine = slots + ((size_t)(epoch & 1) * W + wg) * slotG;
-        publish_dots();                    // wave 0, from the partials stored before the last barrier: the dots leave FIRST, nobody waits
-        const T m = lane_on ? row_times_window<T, S, SP>(pm, &xw[jl * SP]) : (T)0;       // m = Pinv w (own + ghost-lane knots)
-        if (lane_on) xm[jl * SP + r_] = m;
-        __syncthreads();
-        const T n = own ? row_times_window<T, S, SP>(sm, &xm[(jl - 1) * SP]) : (T)0;     // n = S m
-        publish_blocks(n);
-        collect(true, gamma_, delta);
-        if (aborted) break;
-        if (rec) a.eta_hist[it] = (double)gamma_;
-        if (it > 0 && fabs(gamma_) < tol) { iters = it - 1; break; }                      // gato_pcg.cuh:404-411 (eta' after update it - 1)
-        if (it == a.max_iters) break;
-        if (it == 0) { beta = (T)0; alpha = quotient(gamma_, delta); }
-        else {
-            beta = quotient(gamma_, gamma_old);
-            alpha = quotient(gamma_, delta - quotient(beta * gamma_, alpha));
-        }
-        gamma_old = gamma_;
-        z = n + beta * z;
-        q = m + beta * q;
-        s = w + beta * s;
-        p = u + beta * p;
-        lam += alpha * p;
-        r -= alpha * s;
-        u -= alpha * q;
-        w -= alpha * z;
-        if (own) xw[(jl + 1) * SP + r_] = w;
-        if (W > 1 && ghost_thr) {
-            g_z = gw[gb][ge] + beta * g_z;
-            g_w -= alpha * g_z;
-            if (ghost_on) xw[gslot * SP + ge] = g_w;
-        }
-        partials_store(wpart[(epoch + 1) & 1][0], wave, lane, own ? r * u : (T)0);       // the NEXT iteration's dots, in front of its barrier
-        partials_store(wpart[(epoch + 1) & 1][1], wave, lane, own ? w * u : (T)0);
-        __syncthreads();
-    }
-    if (own) dL[(size_t)k * S + r_] = lam;
-    if (wg == 0 && tid == 0) {
-        a.iters[sys] = aborted ? -1 : iters;
-        if (a.final_eta && sys == 0) *a.final_eta = (double)gamma_;
-    }
-}
-
+// (Round 4 also had a PIPELINED recurrence here (Ghysels-Vanroose, pcg_variant = 2: the all-to-all of the dots travelling behind the
+// two products).  Measured no gain over this kernel on any shape - 14/7/4096 f32 2.78 us per iteration against 2.70, 32/16/1024 3.99 /
+// 3.26, 14/7/4096 f64 4.16 against the default's 4.13 - because the neighbours' boundary blocks can only be published after the
+// products that form them, so one exchange latency stays exposed either way (DESIGN_LOG.md R4.5).  Removed in round 5.)
 template <typename T, int S> struct Cg1Threads {
     static constexpr int regs = (6 * S + 3 * S) * (int)(sizeof(T) / 4) + 48;
     static constexpr int v = regs <= 128 ? 1024 : regs <= 168 ? 768 : regs <= 256 ? 512 : 256;
@@ -562,21 +489,32 @@ template <typename T, int S>
 int pcg_cg1_max_threads() { return Cg1Threads<T, S>::v; }
 
 template <typename T, int S>
-int launch_pcg_cg1(const PcgLaunch &a, hipStream_t st)
+int launch_pcg_cg1(const PcgLaunch &a0, hipStream_t st)
 {
     constexpr int MAXT = Cg1Threads<T, S>::v;
+    const bool mr = a0.xslots != nullptr;                   // one rank of a cluster launch
+    PcgLaunch a = a0;
+    if (!mr) { a.k_begin = 0; a.k_end = a.K; a.rank = 0; a.nranks = 1; }
+    const int Kl = a.k_end - a.k_begin;                     // knots this launch works on
+    if (mr && (a.batch > 1 || a.xcd_pack || a.nranks < 1 || a.nranks > GATO_MAX_RANKS || a.rank < 0 || a.rank >= a.nranks ||
+               a.k_begin < 0 || Kl < 1 || a.k_end > a.K || (a.rank == 0) != (a.k_begin == 0) || (a.rank == a.nranks - 1) != (a.k_end == a.K))) {
+        set_error("pcg_cg1(cluster): bad shard rank=%d/%d knots [%d,%d) of %d", a.rank, a.nranks, a.k_begin, a.k_end, a.K);
+        return GATO_EINVAL;
+    }
     const int lanes_needed = (a.knots_per_wg + 2) * S;
+    // (every workgroup hands its first / last TWO blocks of w to its neighbours: two knots each, whenever the solve has neighbours)
+    const bool neighbours = a.groups > 1 || (mr && a.nranks > 1);
     if (a.threads > MAXT || a.threads % 64 != 0 || a.threads < 4 * S || lanes_needed > a.threads || a.groups < 1 ||
-        a.groups > 256 || (long long)a.groups * a.knots_per_wg < a.K || (long long)(a.groups - 1) * a.knots_per_wg >= a.K ||
-        (a.groups > 1 && (a.knots_per_wg < 2 || a.K - (a.groups - 1) * a.knots_per_wg < 2))) {
-        set_error("pcg_cg1: bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d max=%d)", a.K, a.groups,
+        a.groups > 256 || (long long)a.groups * a.knots_per_wg < Kl || (long long)(a.groups - 1) * a.knots_per_wg >= Kl ||
+        (neighbours && (a.knots_per_wg < 2 || Kl - (a.groups - 1) * a.knots_per_wg < 2))) {
+        set_error("pcg_cg1: bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d max=%d)", Kl, a.groups,
                   a.knots_per_wg, a.threads, MAXT);
         return GATO_EINVAL;
     }
     if (a.batch > 1 && a.groups != 1) { set_error("pcg_cg1: a batch needs one workgroup per system"); return GATO_EINVAL; }
     if (a.ev_start) GATO_HIP_CHECK(hipEventRecord(a.ev_start, st));
     const int nblocks = a.batch > 1 ? a.batch : (a.xcd_pack > 0 ? 8 * ((a.groups + a.xcd_pack - 1) / a.xcd_pack) : a.groups);
-    if (a.pipelined) hipLaunchKernelGGL((pcg_pipe_kernel<T, S, MAXT>), dim3(nblocks), dim3(a.threads), 0, st, a);
+    if (mr) hipLaunchKernelGGL((pcg_cg1_kernel<T, S, MAXT, true>), dim3(nblocks), dim3(a.threads), 0, st, a);
     else hipLaunchKernelGGL((pcg_cg1_kernel<T, S, MAXT>), dim3(nblocks), dim3(a.threads), 0, st, a);
     GATO_HIP_CHECK(hipGetLastError());
     if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));

@@ -95,6 +95,48 @@ template <typename T> using GranuleSys = GranuleT<T, __HIP_MEMORY_SCOPE_SYSTEM>;
 
 constexpr int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
+// ---- cluster launches (MR kernels), at exit: lambda_{k_end} for the dz back-substitution of the rank's last knot -------------
+// dz_{x,k} = Q_k^-1 (q_k - lambda_k - A_k^T lambda_{k+1}) (gato_schur.cuh:833-852): the last knot of a rank needs the FIRST lambda
+// block of the right neighbour rank.  Every rank but the first stores that block into its left neighbour's mirror (system-scope
+// peer stores, {tag, payload} granules at a.lam_off, tag = a.lam_tag: unique per launch, identical on all ranks); the last
+// workgroup of every rank but the last polls its OWN mirror for it (bounded) and writes it to dL[k_end] - the row behind the
+// rank's own slice of the full-length lambda array - where the dz launch that follows on the stream finds it.  Call after the
+// workgroup has stored its lambda rows, from every thread.  Returns false if the wait timed out (status word set).
+template <typename T, int S>
+__device__ __forceinline__ bool cluster_lambda_ghost(const PcgLaunch &a, int wg, int W, T *__restrict__ dL, bool aborted)
+{
+    typedef GranuleSys<T> XGr;
+    constexpr int GPV = XGr::GPV;
+    if (a.lam_tag == 0u || a.nranks <= 1) return true;
+    const int tid = threadIdx.x;
+    __syncthreads();                                    // the workgroup's lambda rows are stored (block 0 by lanes of any wave)
+    bool ok = true;
+    if (wg == 0 && a.rank > 0 && tid < S) {
+        const T v = dL[(size_t)a.k_begin * S + tid];
+        XGr::store((gu64 *)a.xpeer[a.rank - 1] + a.lam_off + tid * GPV, a.lam_tag, v);
+    }
+    if (wg == W - 1 && a.rank < a.nranks - 1 && tid < 64 && !aborted) {
+        const int l = tid < S ? tid : 0;
+        gu64 *src = (gu64 *)a.xslots + a.lam_off + l * GPV;
+        unsigned long long raw[GPV];
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spin = 0;; ++spin) {
+            bool got = true;
+#pragma unroll
+            for (int g = 0; g < GPV; ++g) {
+                raw[g] = __hip_atomic_load(src + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                got &= (unsigned)(raw[g] >> 32) == a.lam_tag;
+            }
+            if (__all(got)) break;
+            if ((spin & 255u) == 255u && __builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { ok = false; break; }
+        }
+        if (ok) {
+            if (tid < S) dL[(size_t)a.k_end * S + tid] = XGr::decode(raw);
+        } else if (tid == 0) __hip_atomic_store((gi32 *)a.status, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return ok;
+}
+
 // LDS hand-over inside ONE wave (a lane reads what another lane of the same wave wrote): the wave's LDS operations execute in
 // order, so all that is needed is that the compiler keeps them in order too.
 __device__ __forceinline__ void wave_lds_fence()

@@ -32,6 +32,16 @@ constexpr int largest_divisor_upto(int n, int cap)
     return best;
 }
 
+// fp64 at S = 32: builds (-DGATO_DMA_F64_S32=1: 206 / 214 VGPRs, no spill, with the row read in chunks below) and
+// is correct (rel diff 6e-16 against the launch without resident rows), but LOSES by 2.6x: a block row is 24 KB, so a tile is ONE
+// block row (two would leave no LDS for the window), 32 of the 384 computing lanes work per tile step and a step is that half
+// wave's chain of 96 dependent fp64 FMAs behind a barrier.  Measured (profiles/r05_ring_crossover.log, us per iteration): 32/16/4096
+// ring 98.1 against 34.2 without resident rows, 8192: 187.6 / 76.3, 16384: 365.8 / 141.0 - the latter is 6.1 TB/s of algorithmic
+// bytes (0.76 of 8 TB/s) already.  Not built by default; what would beat 0.76 is a tile step that uses all lanes (12 lanes per row
+// and a cross-lane sum: another summation order), not this ring.
+#ifndef GATO_DMA_F64_S32
+#define GATO_DMA_F64_S32 0
+#endif
 template <typename T, int S>
 struct DmaCfg {
     static constexpr int VW = VecOf<T>::W;
@@ -57,12 +67,13 @@ struct DmaCfg {
     static constexpr int NHI = (PIECES + 6) / 7, NLO = PIECES / 7;      // DMA instructions per tile of a worker wave: NHI or NLO
     // rounds = rows per worker lane: by registers (r, p, lambda, y per row beside the 3S matrix entries of the row being
     // multiplied) and by the LDS the operand window takes beside the ring
-    static constexpr int XR_REG = S <= 16 ? (sizeof(T) == 4 ? 16 : 8) : (sizeof(T) == 4 ? 12 : 4);   // S = 32 fp32: 241 VGPRs at 12 rows, spills at 16
+    static constexpr int XR_REG = S <= 16 ? (sizeof(T) == 4 ? 16 : 8) : 12;   // S = 32 fp32: 241 VGPRs at 12 rows, spills at 16
     static constexpr int XR_LDS = (150 * 1024 - NB * TILE_BYTES - 2 * SP * (int)sizeof(T)) / (KPR * SP * (int)sizeof(T));
     static constexpr int XR = XR_REG < XR_LDS ? XR_REG : XR_LDS;
     static constexpr int MAXK = XR * KPR;                               // knots per workgroup (S = 14: fp32 512 - K <= 131 072 on 256 CUs - fp64 256)
+    static constexpr bool BLOCKWISE = 3 * S * (int)(sizeof(T) / 4) > 128;   // the row's entries leave the tile block by block (registers)
     static constexpr bool OK = WL % S == 0 && WL <= 448 && KPR % TK == 0 && 2 * S <= 64 && S >= 8 && TILE_BYTES <= 48 * 1024 && XR >= 2 &&
-                               !(S > 16 && sizeof(T) == 8);              // fp64 at S = 32: 192 registers of matrix row alone - not built
+                               (GATO_DMA_F64_S32 || !(S > 16 && sizeof(T) == 8));   // fp64 at S = 32: see GATO_DMA_F64_S32
 };
 
 // MR: one rank of a cluster launch (gato_cluster_pcg) - the second hand-off level of pcg_resident_kernel<..., MR>: the rank's
@@ -208,6 +219,38 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
                 issue(G + AHEAD);
                 const int j = jl + KPR * e;
                 const bool mine = cw && wl >= sub * Cfg::TROWS && wl < (sub + 1) * Cfg::TROWS && j < nk;
+                if constexpr (Cfg::BLOCKWISE) {
+                    // a row of 3S doubles at S = 32 is 192 VGPRs: in chunks of 16 columns instead (16 entries out of the tile + their
+                    // window entries, then the 16 FMAs; the same left-to-right order, gato_utils.cuh:177-183).  A real loop: unrolled,
+                    // the scheduler hoists every chunk's reads in front of the one dependent FMA chain and spills 160 registers
+                    if (mine) {
+                        typedef typename VecOf<T>::type V;
+                        constexpr int VW = VecOf<T>::W, CH = 16;
+                        static_assert(S % CH == 0 && SP == S, "whole chunks per block");
+                        const unsigned ts = G % NB;
+                        const T *mrow = &tiles[ts][(jl % TK) * ROW + rr];
+                        const T *xw = &win[j * SP];
+                        const bool nl = k0 + j == 0, nr = k0 + j == K - 1;
+                        T acc = (T)0;
+#pragma unroll 1
+                        for (int c0 = 0; c0 < 3 * S; c0 += CH) {
+                            T mb[CH];
+#pragma unroll
+                            for (int c = 0; c < CH; ++c) mb[c] = mrow[(c0 + c) * S];
+                            const bool drop = (c0 < S && nl) || (c0 >= 2 * S && nr);     // never written blocks (gato_utils.cuh:157-174)
+#pragma unroll
+                            for (int i = 0; i < CH / VW; ++i) {
+                                const V v = *reinterpret_cast<const V *>(xw + c0 + i * VW);
+#pragma unroll
+                                for (int e = 0; e < VW; ++e) acc = gato::fmaT(drop ? (T)0 : mb[i * VW + e], v[e], acc);
+                            }
+                        }
+                        y[e] = acc;
+                        dot = gato::fmaT(x[e], acc, dot);
+                    }
+                    ++G;
+                    continue;
+                }
                 // all 3S entries of the row out of the tile first (independent LDS reads in flight together), then the FMAs
                 T m[3 * S];
                 if (mine) {
@@ -401,6 +444,7 @@ __global__ __launch_bounds__(512) void pcg_dma_kernel(PcgLaunch a)
         const int j = jl + KPR * e;
         if (cw && j < nk) dL[(size_t)(k0 + j) * S + rr] = lam[e];               // :433-435
     }
+    if constexpr (MR) (void)cluster_lambda_ghost<T, S>(a, wg, W, dL, aborted);      // lambda_{k_end} for this rank's dz launch
     if (wg == 0 && tid == 0) {
         a.iters[0] = aborted ? -1 : iters;
         if (a.final_eta) *a.final_eta = (double)eta_new;

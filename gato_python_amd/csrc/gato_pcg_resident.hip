@@ -1084,6 +1084,7 @@ __global__ __launch_bounds__(MAXT) void pcg_resident_kernel(PcgLaunch a)
         const int q = tid + e * (int)blockDim.x;
         if (q < n_ext_rows) dL[(size_t)(k0 + xk) * S + q] = xst[0][q];
     }
+    if constexpr (MR) (void)cluster_lambda_ghost<T, S>(a, wg, W, dL, aborted);      // lambda_{k_end} for this rank's dz launch
     // ---- dz back-substitution in the same launch (one-workgroup launches: every lambda_k is here).  Same formulas and
     // accumulation order as dz_kernel (gato_assembly.hip; gato_schur.cuh:758-867, D2 fixed): bit-identical results.
     if constexpr (XR == 0 && !MR) {

@@ -20,7 +20,8 @@ ClusterPCG is the xGMI-native transport (whole solve: linsys_solve_cluster; lins
 connected and falls back to linsys_solve_sharded otherwise): ONE persistent launch per rank
 per solve, in which the exchange above happens inside the kernel - every rank stores its {epoch, payload}
 granules straight into the peers' IPC-mapped mirrors (system-scope stores over xGMI) and polls only its own
-(gato_cluster_* in include/gato_hip.h, pcg_resident_kernel<..., MR>).  torch.distributed carries the 64-byte
+(gato_cluster_* in include/gato_hip.h, pcg_resident_kernel<..., MR>; option variant = 1: pcg_cg1_kernel<..., MR>, one
+exchange per iteration).  torch.distributed carries the 64-byte
 IPC handles once and the barrier after connecting; nothing of it runs inside the solve.  The all-gather
 schedule above (two launches + two RCCL collectives per iteration, linsys_solve_sharded) stays as the portable
 fallback.  connect_cluster() is the one place that decides: mirrors in each memory kind in turn, a probe solve, every
@@ -300,6 +301,16 @@ class ClusterPCG:
         self._lib.check(self._lib.lib().gato_cluster_pcg(self.sol._h, p(Sb), p(Pb), p(gamma), p(lam), float(exit_tol),
                                                          int(max_iters), p(iters), st))
 
+    def linsys(self, d, exit_tol, max_iters, rho, lam, dz, iters, stream=None):
+        """Enqueue this rank's part of a WHOLE solve (gato_cluster_linsys): the stage kernels on the knots its shard reads, its
+        persistent launch, dz on its range - one call, nothing on the host or in a collective in between.  d: the device inputs
+        of Solver.upload_system (replicated on every rank); lam / dz: full-length buffers, this rank's rows are written."""
+        st = self.sol._stream() if stream is None else ct.c_void_p(stream)
+        p = lambda t: ct.c_void_p(t.data_ptr())
+        self._lib.check(self._lib.lib().gato_cluster_linsys(self.sol._h, p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(d[5]), p(d[6]),
+                                                            p(d[7]), float(exit_tol), int(max_iters), float(rho), p(lam), p(dz),
+                                                            p(iters), st))
+
     def close(self):
         if self.sol is not None and self.sol._h:
             self._lib.lib().gato_cluster_destroy(self.sol._h)
@@ -341,51 +352,6 @@ def run_cluster_lockstep(solvers, Sb, Pb, gamma, exit_tol, max_iters):
     for c in cl:
         c.close()
     return lam, out
-
-
-def assemble_shard(sol, d, rho, k0, k1, out=None):
-    """Stage kernels restricted to what the PCG shard [k0, k1) of this rank reads (full-size buffers, only these rows
-    are written): S / Pinv rows k0..k1-1 complete (S[k].right comes from the Schur step of knot k+1, the stair blocks
-    need theta^-1 of both neighbours) and gamma on k0-1..k1 (ghosts of the initial residual).  Hence
-    gather + inversions on [k0-2, k1+1), Schur on [k0-1, k1+1), stair on [k0, k1).  Returns (Gd, Cd, Sb, Pb, gamma, Ginv)."""
-    K = sol.K
-    clip = lambda a: max(0, min(K, a))
-
-    def rng(lo, hi):
-        sol.set_option("knot_lo", clip(lo))
-        sol.set_option("knot_hi", clip(hi))
-    if out is None:
-        import torch
-        z = lambda n: torch.zeros(int(max(n, 1)), dtype=sol.dtype, device=f"cuda:{sol.device}")
-        out = dict(Gd=z(sol.sizes["G_dense"]), Cd=z(sol.sizes["C_dense"]), Sb=z(sol.sizes["bd"]), Pb=z(sol.sizes["bd"]),
-                   gam=z(sol.sizes["sk"]), Gi=z(sol.sizes["G_dense"]))
-    from . import _lib
-    from .solver import _ptr
-    L = _lib.lib()
-    rng(k0 - 2, k1 + 1)
-    _lib.check(L.gato_convert(sol._h, _ptr(d[0]), _ptr(d[1]), _ptr(d[2]), _ptr(d[3]), _ptr(d[4]), _ptr(d[5]), float(rho),
-                              _ptr(out["Gd"]), _ptr(out["Cd"]), sol._stream()))
-    # gato_form_schur inverts the Q_k, R_k of its knot range first: the range must cover knot k-1 of every Schur step, so
-    # the inversions run on [k0-2, k1+1) and the Schur steps on [k0-1, k1+1) (their extra first knot only rewrites the
-    # rows k0-2 of S / Pinv, which nobody reads)
-    _lib.check(L.gato_form_schur(sol._h, _ptr(out["Gd"]), _ptr(out["Cd"]), _ptr(d[6]), _ptr(d[7]), _ptr(out["Sb"]), _ptr(out["Pb"]),
-                                 _ptr(out["gam"]), _ptr(out["Gi"]), sol._stream()))
-    rng(k0, k1)
-    _lib.check(L.gato_form_ss(sol._h, _ptr(out["Sb"]), _ptr(out["Pb"]), sol._stream()))
-    rng(0, 0)
-    return out
-
-
-def dz_shard(sol, d, bufs, lam, dz, k0, k1):
-    """dz rows of the knots [k0, k1) into the full-size buffer dz (lam: the assembled lambda - knot k needs lambda_{k+1})."""
-    from . import _lib
-    from .solver import _ptr
-    sol.set_option("knot_lo", k0)
-    sol.set_option("knot_hi", k1)
-    _lib.check(_lib.lib().gato_compute_dz(sol._h, _ptr(bufs["Gi"]), _ptr(bufs["Cd"]), _ptr(d[6]), _ptr(lam), _ptr(dz), sol._stream()))
-    sol.set_option("knot_lo", 0)
-    sol.set_option("knot_hi", 0)
-    return dz
 
 
 MIRROR_KINDS = ("uncached", "finegrained", "plain")
@@ -467,47 +433,122 @@ class ClusterTimeout(ClusterUnavailable):
     """A hand-off of a cluster solve timed out on some rank (raised on every rank alike; the outputs are not valid)."""
 
 
-def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None, state=None, check=True):
-    """Whole solve with the PCG sharded over the ranks of `group` through the in-kernel xGMI hand-off.  Assembly is SHARDED
-    too (assemble_shard: every rank forms the block rows its PCG shard reads plus the few halo knots they depend on), each
-    rank's launch solves its knot range, lambda and dz are assembled by one sum-all-reduce of the disjoint slices each per
-    solve (outside the iteration loop).  The first call connects the cluster (connect_cluster: memory kinds in turn, a
-    probe solve, ClusterUnavailable on every rank when the transport cannot be used).  With check (default) the call
-    synchronises at its end and raises ClusterTimeout on EVERY rank if any rank's launch reported a hand-off time-out
-    (iters = -1 / sticky status): the outputs are garbage then and the caller takes linsys_solve_sharded.
-    `state` (returned as the last element) carries solver, device inputs and the connected cluster across calls."""
+class _GatherPlan:
+    """lambda and dz of a sharded solve onto every rank with ONE all-gather of a fixed-size record per rank
+
+          record = [ lambda rows of the rank's knots | dz rows of the rank's knots ]   (padded to the largest range)
+
+    into buffers allocated once (no per-solve allocation, no zero-padded full-length sums): two slice copies into the send
+    record, the collective, two index gathers out of the received records."""
+
+    def __init__(self, sol, nranks, rank, device):
+        import torch
+        S, n, K = sol.S, sol.n, sol.K
+        self.ranges = knot_ranges(K, nranks)
+        mk = max(k1 - k0 for k0, k1 in self.ranges)
+        self.nl, self.nd = mk * S, mk * n
+        self.rec = self.nl + self.nd
+        self.k0, self.k1 = self.ranges[rank]
+        self.send = torch.zeros(self.rec, dtype=sol.dtype, device=device)
+        self.recv = torch.zeros(self.rec * nranks, dtype=sol.dtype, device=device)
+        il, iz = np.empty(S * K, np.int64), np.empty(sol.N, np.int64)
+        for r, (k0, k1) in enumerate(self.ranges):
+            il[k0 * S:k1 * S] = r * self.rec + np.arange((k1 - k0) * S)
+            hi = min(k1 * n, sol.N)
+            iz[k0 * n:hi] = r * self.rec + self.nl + np.arange(hi - k0 * n)
+        self.il, self.iz = torch.from_numpy(il).to(device), torch.from_numpy(iz).to(device)
+        self.lam_out = torch.empty(S * K, dtype=sol.dtype, device=device)
+        self.dz_out = torch.empty(sol.N, dtype=sol.dtype, device=device)
+        self.S, self.n, self.N = S, n, sol.N
+
+    def gather(self, lam, dz, group=None):
+        import torch
+        import torch.distributed as dist
+        S, n = self.S, self.n
+        hi = min(self.k1 * n, self.N)
+        self.send[:(self.k1 - self.k0) * S].copy_(lam[self.k0 * S:self.k1 * S])
+        self.send[self.nl:self.nl + hi - self.k0 * n].copy_(dz[self.k0 * n:hi])
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(self.recv, self.send, group=group)
+        else:                                             # one-GPU rehearsals over gloo: through host memory
+            ho, hs = self.recv.cpu(), self.send.cpu()
+            dist.all_gather_into_tensor(ho, hs, group=group)
+            self.recv.copy_(ho)
+        torch.index_select(self.recv, 0, self.il, out=self.lam_out)
+        torch.index_select(self.recv, 0, self.iz, out=self.dz_out)
+        return self.lam_out, self.dz_out
+
+
+def close_state(state):
+    """Frees what a state dict of linsys_solve_cluster / linsys_solve_auto owns (mirrors, solver arenas)."""
+    if not state:
+        return
+    for key in ("cl", "sol", "rccl_sol"):
+        obj = state.pop(key, None)
+        try:
+            if obj is not None:
+                obj.close()
+        except Exception:     # noqa: BLE001
+            pass
+
+
+def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None, state=None, check=True,
+                         gather=True, variant=0, solver_options=None):
+    """Whole solve with the PCG sharded over the ranks of `group` through the in-kernel xGMI hand-off.  Per solve every rank
+    makes ONE library call (ClusterPCG.linsys -> gato_cluster_linsys: sharded assembly, its persistent launch, dz on its knot
+    range - lambda_{k1}, the one block dz needs from the neighbouring rank, arrives inside the launch) and, with gather (default),
+    one all-gather of [lambda rows | dz rows] records into buffers allocated at the first call (_GatherPlan); gather=False leaves
+    lambda and dz sharded (full-length buffers of which this rank's rows are valid).  variant = 1: the single-reduction
+    recurrence - ONE cross-GPU exchange per iteration instead of two (opt-in as on one GPU: rounding differs from the
+    reference recurrence).  The first call connects the cluster (connect_cluster: memory kinds in turn, a probe solve,
+    ClusterUnavailable on every rank when the transport cannot be used).  With check (default) the call synchronises at its end
+    and raises ClusterTimeout on EVERY rank if any rank's launch reported a hand-off time-out (iters = -1 / sticky status): the
+    outputs are garbage then and the caller takes linsys_solve_sharded.  `state` (returned as the last element) carries solver,
+    device inputs, output buffers and the connected cluster across calls; a later call with ANOTHER system of the same shape
+    copies its values into the same device buffers.  close_state(state) frees it.  solver_options: {option: value} set on
+    the solver before the cluster is connected (the same on every rank)."""
     import torch
     import torch.distributed as dist
     from .solver import Solver
     rank, nranks = dist.get_rank(group), dist.get_world_size(group)
+    created_here = state is None
     if state is None:
         dev = torch.cuda.current_device() if device is None else device
         sol = Solver(sysm.S, sysm.C, sysm.K, dtype, dev)
-        state = dict(sol=sol, d=sol.upload_system(sysm))
+        sol.set_option("pcg_variant", int(variant))
+        for name, value in (solver_options or {}).items():      # before connecting: every rank plans with the same options
+            sol.set_option(name, value)
+        tdev = f"cuda:{sol.device}"
+        state = dict(sol=sol, d=sol.upload_system(sysm), sysm=sysm, variant=int(variant),
+                     lam=torch.zeros(sol.S * sol.K, dtype=sol.dtype, device=tdev),
+                     dz=torch.zeros(sol.N, dtype=sol.dtype, device=tdev),
+                     iters=torch.zeros(1, dtype=torch.int32, device=tdev))
 
         def probe(cl):
-            b = state["bufs"] = assemble_shard(sol, state["d"], sysm.rho, cl.k0, cl.k1, state.get("bufs"))
-            lam = torch.zeros(sol.S * sol.K, dtype=sol.dtype, device=b["Sb"].device)
-            it = torch.zeros(1, dtype=torch.int32, device=b["Sb"].device)
-            cl.pcg(b["Sb"], b["Pb"], b["gam"], exit_tol, max_iters, lam, it)
-            return it
+            cl.linsys(state["d"], exit_tol, max_iters, sysm.rho, state["lam"], state["dz"], state["iters"])
+            return state["iters"]
         try:
             state["cl"], state["rejected"] = connect_cluster(sol, rank, nranks, probe, group)
         except ClusterUnavailable:
             sol.close()
             raise
-    created_here = "transport" not in state and state.get("_fresh", True)
-    state["_fresh"] = False
+        state["plan"] = _GatherPlan(sol, nranks, rank, tdev)
     sol, d, cl = state["sol"], state["d"], state["cl"]
-    b = state["bufs"] = assemble_shard(sol, d, sysm.rho, cl.k0, cl.k1, state.get("bufs"))
-    dev = b["Sb"].device
-    lam = torch.zeros(sol.S * sol.K, dtype=sol.dtype, device=dev)
-    dz = torch.zeros(sol.N, dtype=sol.dtype, device=dev)
-    iters = torch.zeros(1, dtype=torch.int32, device=dev)
-    cl.pcg(b["Sb"], b["Pb"], b["gam"], exit_tol, max_iters, lam, iters)
-    allreduce_sum_(lam, group)                      # disjoint slices -> the whole lambda on every rank (once per solve)
-    dz_shard(sol, d, b, lam, dz, cl.k0, cl.k1)
-    allreduce_sum_(dz, group)
+    if (sysm.S, sysm.C, sysm.K) != (sol.S, sol.C, sol.K) or np.dtype(dtype) != sol.np_dtype:
+        raise ValueError("linsys_solve_cluster: the state belongs to another shape / dtype; close_state() it and start anew")
+    if int(variant) != state["variant"]:
+        sol.set_option("pcg_variant", int(variant))
+        state["variant"] = int(variant)
+    if sysm is not state["sysm"]:                      # new values, same shape: into the same device buffers
+        for t, a in zip(d, (sysm.G_row, sysm.G_col, sysm.G_val, sysm.C_row, sysm.C_col, sysm.C_val, sysm.g, sysm.c)):
+            if t.numel() != np.asarray(a).size:
+                raise ValueError("linsys_solve_cluster: the sparsity pattern changed; close_state() the state and start anew")
+            t.copy_(torch.from_numpy(np.ascontiguousarray(a, {torch.int32: np.int32}.get(t.dtype, sol.np_dtype))))
+        state["sysm"] = sysm
+    lam, dz, iters = state["lam"], state["dz"], state["iters"]
+    cl.linsys(d, exit_tol, max_iters, sysm.rho, lam, dz, iters)
+    if gather:
+        lam, dz = state["plan"].gather(lam, dz, group)
     if check:
         sol.synchronize()
         ok = int(iters.cpu()[0]) >= 0
@@ -517,33 +558,30 @@ def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=Non
             ok = False
         if not _all_ranks_ok(ok, group):
             if created_here:        # the caller never saw this state: nobody else can free the mirrors and the arena
-                try:
-                    cl.close()
-                    sol.close()
-                except Exception:     # noqa: BLE001
-                    pass
+                close_state(state)
             raise ClusterTimeout("a hand-off of the cluster solve timed out" + ("" if ok else " on this rank"))
     return lam, dz, iters, state
 
 
-def linsys_solve_auto(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None, state=None):
+def linsys_solve_auto(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None, state=None, variant=0):
     """The product entry for a knot-sharded solve: the in-kernel transport when it can be connected and its solves come
     back complete, else (every rank together) the RCCL all-gather schedule.  Returns (lambda, dz, iters, state);
-    state["transport"] says what ran."""
+    state["transport"] says what ran; close_state(state) frees what it holds."""
     if state is None or state.get("transport") == "xgmi":
         try:
-            lam, dz, iters, st = linsys_solve_cluster(sysm, exit_tol, max_iters, dtype, device, group, state)
+            lam, dz, iters, st = linsys_solve_cluster(sysm, exit_tol, max_iters, dtype, device, group, state, variant=variant)
             st["transport"] = "xgmi"
             return lam, dz, iters, st
         except ClusterUnavailable as e:
-            if state is not None:                   # a connected cluster timed out later: drop it, keep going over RCCL
-                try:
-                    state["cl"].close()
-                    state["sol"].close()
-                except Exception:     # noqa: BLE001
-                    pass
+            close_state(state)                       # a connected cluster timed out later: drop it, keep going over RCCL
             state = dict(transport="rccl", why=str(e)[:300])
-    # the RCCL schedule keeps its solver across calls (state["rccl_sol"]): a new one per call would run the calibration trials again
-    lam, dz, iters, sol = linsys_solve_sharded(sysm, exit_tol, max_iters, dtype, device, group, sol=state.get("rccl_sol"))
+    # the RCCL schedule keeps its solver across calls (state["rccl_sol"]): a new one per call would run the calibration trials
+    # again - but only for the shape, type and device it was made for
+    sol = state.get("rccl_sol")
+    if sol is not None and ((sol.S, sol.C, sol.K) != (sysm.S, sysm.C, sysm.K) or sol.np_dtype != np.dtype(dtype) or
+                            (device is not None and sol.device != int(device))):
+        sol.close()
+        sol = state["rccl_sol"] = None
+    lam, dz, iters, sol = linsys_solve_sharded(sysm, exit_tol, max_iters, dtype, device, group, sol=sol)
     state["rccl_sol"] = sol
     return lam, dz, iters, state

@@ -1,11 +1,13 @@
 """bench.py legs for more than one GPU.  One process per GPU, launched by torch.distributed.run.
 
-Default (--gpus N, no --workload): the N = 1 workload (BASELINE.json configs[1], IIWA 14/7/50 fp64 whole step) on
-every rank, each rank its own system, no data-path collective: weak scaling, value = all ranks' PCG iterations / s,
-directly comparable with the N = 1 line ("replicas": that shape is one workgroup on one CU, it does not shard).  The
-same JSON line carries, as "sharded", the knot-sharded solves that DO exchange data - configs[3] (IIWA 14/7, K = 4096)
-and K = 262144 (the size where splitting can pay) split over the ranks, strong scaling: a step = replicated assembly +
-sharded PCG of exactly 100 iterations + dz (xgmi transport: assembly and dz sharded too) - each with its us per iteration next to the same system on ONE GPU.
+Default (--gpus N, no --workload): the last line is LED BY THE SHARDED SYSTEM - `value` = PCG iterations/s of ONE IIWA
+14/7/4096 system (BASELINE configs[3]) knot-sharded over the N GPUs, whole steps (sharded assembly + sharded PCG of exactly
+100 iterations + sharded dz + the gather of lambda / dz), "scaling": "strong", with the same system on one GPU beside it
+(`one_gpu_value`, `sharded_speedup`).  The N = 1 workload (BASELINE configs[1], IIWA 14/7/50 fp64 whole step) runs on every
+rank first, each rank its own system, no data-path collective (weak scaling: that shape is one workgroup on one CU, it does
+not shard): it is printed as an EARLIER line and rides in the last one under `replicas`.  configs[4] (32/16/1024) and
+K = 262144 (the size where splitting can pay) ride under `config.sharded`, each with its us per iteration next to the same
+system on ONE GPU.
 Transport of the sharded PCG: "xgmi" = ONE persistent launch per rank with the dot + halo exchange inside the kernel
 (peer stores into IPC-mapped mirrors, gato_cluster_*); if the mirrors cannot be mapped or the first solve times out,
 "rccl" = two launches + two RCCL all-gathers per iteration (gato_shard_pcg_*).  The line says which one ran.
@@ -125,95 +127,101 @@ from .dist import first_working_kind          # noqa: E402,F401  (tests import i
 
 
 def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
+    """One knot-sharded system over the ranks, strong scaling.  A step = this rank's sharded assembly + its persistent launch
+    (exactly MAX_ITERS iterations) + dz on its knots (ONE library call, gato_cluster_linsys) + one all-gather of the lambda / dz
+    rows (dist._GatherPlan).  Timed for the default recurrence (two in-kernel exchanges per iteration: `value`) and for the
+    single-reduction recurrence (one exchange: "single_reduction"), with the outputs gathered and left sharded."""
     from . import synth
-    from .dist import (ClusterUnavailable, HipShardBackend, ShardedPCG, allreduce_sum_, assemble_shard, connect_cluster,
-                       dz_shard)
+    from .dist import ClusterUnavailable, HipShardBackend, ShardedPCG, close_state, linsys_solve_cluster
     from .solver import Solver
     S, C, K, dt = WORKLOADS[name]
     sysm = synth.make_system(S, C, K, seed=0)
-    sol = Solver(S, C, K, dt, local)
-    if ONE_GPU:
-        sol.set_option("max_workgroups", max(1, 240 // world))
-    d = sol.upload_system(sysm)
-    dev = f"cuda:{local}"
     want = os.environ.get("GATO_SHARD_TRANSPORT", "xgmi")
-    transport, why, cl = "rccl", "", None
+    transport, why, state, sol = "rccl", "", None, None
+    opts = {"max_workgroups": max(1, 240 // world)} if ONE_GPU else {}
 
-    def assemble():
-        Gd, Cd = sol.convert(*d[:6], sysm.rho)
-        Sb, Pb, gam, Gi = sol.form_schur(Gd, Cd, d[6], d[7])
-        sol.form_ss(Sb, Pb)
-        return Cd, Sb, Pb, gam, Gi
-
-    xb = {}
-
-    def step_xgmi():
-        # every rank assembles only the block rows its shard reads; lambda and dz are assembled by one sum-all-reduce each
-        # per solve (disjoint slices), outside the iteration loop
-        b = xb["b"] = assemble_shard(sol, d, sysm.rho, cl.k0, cl.k1, xb.get("b"))
-        lam = torch.zeros(S * K, dtype=sol.dtype, device=dev)
-        dz = torch.zeros(sol.N, dtype=sol.dtype, device=dev)
-        iters = torch.zeros(1, dtype=torch.int32, device=dev)
-        cl.pcg(b["Sb"], b["Pb"], b["gam"], 0.0, MAX_ITERS, lam, iters)
-        allreduce_sum_(lam)
-        dz_shard(sol, d, b, lam, dz, cl.k0, cl.k1)
-        allreduce_sum_(dz)
-        return lam, dz, iters
-
-    def step_rccl():
-        Cd, Sb, Pb, gam, Gi = assemble()
-        be = HipShardBackend(sol, rank, world, Sb, Pb, gam, 0.0, MAX_ITERS)
-        lam, iters = ShardedPCG(be).solve(MAX_ITERS)
-        return lam, sol.compute_dz(Gi, Cd, d[6], lam), iters
+    def step_xgmi(variant=0, gather=True):
+        return linsys_solve_cluster(sysm, 0.0, MAX_ITERS, dt, local, None, state, check=False, gather=gather, variant=variant)[:3]
 
     if want == "xgmi":
-        def probe(c):
-            # this rank's launch alone (no collective inside): assembly of its rows + the persistent launch
-            b = xb["b"] = assemble_shard(sol, d, sysm.rho, c.k0, c.k1, xb.get("b"))
-            lam = torch.zeros(S * K, dtype=sol.dtype, device=dev)
-            it = torch.zeros(1, dtype=torch.int32, device=dev)
-            c.pcg(b["Sb"], b["Pb"], b["gam"], 0.0, MAX_ITERS, lam, it)
-            return it
         try:
-            cl, why = connect_cluster(sol, rank, world, probe, expect_iters=MAX_ITERS)
-            transport = "xgmi"
+            state = linsys_solve_cluster(sysm, 0.0, MAX_ITERS, dt, local, None, None, check=True, solver_options=opts)[3]
+            transport, why, sol = "xgmi", state.get("rejected", ""), state["sol"]
         except ClusterUnavailable as e:
-            cl, why = None, str(e)[:300]
-            xb.clear()
+            state, why = None, str(e)[:300]
+    if transport != "xgmi":
+        sol = Solver(S, C, K, dt, local)
+        for k_, v_ in opts.items():
+            sol.set_option(k_, v_)
+        d = sol.upload_system(sysm)
+
+        def step_rccl():
+            Gd, Cd = sol.convert(*d[:6], sysm.rho)
+            Sb, Pb, gam, Gi = sol.form_schur(Gd, Cd, d[6], d[7])
+            sol.form_ss(Sb, Pb)
+            be = HipShardBackend(sol, rank, world, Sb, Pb, gam, 0.0, MAX_ITERS)
+            lam, iters = ShardedPCG(be).solve(MAX_ITERS)
+            return lam, sol.compute_dz(Gi, Cd, d[6], lam), iters
     step = step_xgmi if transport == "xgmi" else step_rccl
     el = _timed(lambda: step(), steps, warmup, torch, dist)
     lam, dz, iters = step()
     torch.cuda.synchronize()
-    pcg_us = None
-    if transport == "xgmi":                               # device time of rank 0's launch (it waits for its peers inside)
+    lam, dz = lam.clone(), dz.clone()
+
+    def launch_us(fn):                                    # device time of this rank's launch (it waits for its peers inside)
         sol.set_option("time_pcg", 1)
         ms = []
         for _ in range(5):
             dist.barrier()
-            step()
+            fn()
             ms.append(sol.pcg_last_ms())
         sol.set_option("time_pcg", 0)
-        pcg_us = 1e3 * float(np.mean(ms[1:])) / MAX_ITERS
-    groups, threads, semi = sol.get_option("last_groups"), sol.get_option("last_threads"), sol.get_option("last_semi")
+        return 1e3 * float(np.mean(ms[1:])) / MAX_ITERS
+    pcg_us, extra = None, {}
+    if transport == "xgmi":
+        pcg_us = launch_us(step)
+        groups, threads, semi = sol.get_option("last_groups"), sol.get_option("last_threads"), sol.get_option("last_semi")
+        # the same step with lambda / dz left sharded (no collective at all), and the single-reduction recurrence both ways
+        el_ng = _timed(lambda: step_xgmi(0, False), steps, warmup, torch, dist)
+        extra = {"ms_per_step_outputs_sharded": 1e3 * el_ng / steps, "flat_exchange": bool(sol.get_option("last_cluster_flat"))}
+        try:
+            el1 = _timed(lambda: step_xgmi(1, True), steps, warmup, torch, dist)
+            lam_v1 = step_xgmi(1, True)[0]
+            torch.cuda.synchronize()
+            ran = sol.get_option("last_variant")
+            us1 = launch_us(lambda: step_xgmi(1, True))
+            el1_ng = _timed(lambda: step_xgmi(1, False), steps, warmup, torch, dist)
+            extra["single_reduction"] = {"ran_variant": ran, "iters_per_s": MAX_ITERS * steps / el1, "ms_per_step": 1e3 * el1 / steps,
+                                         "ms_per_step_outputs_sharded": 1e3 * el1_ng / steps, "pcg_us_per_iter": us1,
+                                         "workgroups_per_gpu": sol.get_option("last_groups"), "threads": sol.get_option("last_threads"),
+                                         "flat_exchange": bool(sol.get_option("last_cluster_flat")),
+                                         "lam_rel_diff_vs_default_recurrence": float((lam_v1 - lam).abs().max()) / float(lam.abs().max())}
+        except Exception as e:    # noqa: BLE001  (raised on every rank alike: option and geometry are the same everywhere)
+            extra["single_reduction"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        step_xgmi(0, True)
+        torch.cuda.synchronize()
+    else:
+        groups, threads, semi = sol.get_option("last_groups"), sol.get_option("last_threads"), sol.get_option("last_semi")
     mem_kind = sol.get_option("cluster_mem_kind")
 
     # the same system on ONE GPU (rank 0), for parity and for the strong-scaling ratio of this very shape
     parity = None
     if rank == 0:
         one = Solver(S, C, K, dt, local)
+        d1 = one.upload_system(sysm)
         lam1, dz1 = one.new(S * K), one.new(one.N)
         single = single_us = None
         try:
-            one.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
+            one.linsys(*d1, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
             torch.cuda.synchronize()
             one.check_status()
             for _ in range(2):
-                one.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
+                one.linsys(*d1, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             n1 = 10
             for _ in range(n1):
-                one.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
+                one.linsys(*d1, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
             torch.cuda.synchronize()
             single = MAX_ITERS * n1 / (time.perf_counter() - t1)
             one.set_option("time_pcg", 1)
@@ -223,7 +231,7 @@ def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
                 one.pcg(bufs[0], bufs[1], bufs[2], 0.0, MAX_ITERS, lam=lam1, check=False)
                 mm.append(one.pcg_last_ms())
             single_us = 1e3 * float(np.mean(mm[1:])) / MAX_ITERS
-            one.linsys(*d, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
+            one.linsys(*d1, 0.0, MAX_ITERS, sysm.rho, lam1, dz1)
             torch.cuda.synchronize()
             den = float(lam1.abs().max())
             parity = {"lam_rel_err_vs_single_gpu": float((lam - lam1).abs().max()) / den,
@@ -241,29 +249,36 @@ def sharded_leg(args, torch, dist, rank, local, world, name, steps, warmup):
         w = np.dtype(dt).itemsize
         b_iter = ((6 * K - 4) * S * S + 13 * S * K) * w
         val = MAX_ITERS * steps / el
+        ms_step = 1e3 * el / steps
         out = {"metric": "PCG iterations/s", "value": val, "unit": "iterations/s", "n_gpus": world,
-               "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps,
+               "steps": steps, "warmup": warmup, "ms_per_step": ms_step,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f64" if w == 8 else "f32", "data": "synthetic",
-               "config": {"workload": name, "baseline_config": "configs[3]" if K == 4096 else "beyond BASELINE: the size where sharding pays",
+               "config": {"workload": name, "baseline_config": "configs[3]" if K == 4096 else ("configs[4]" if S == 32 else "beyond BASELINE: the size where sharding pays"),
                           "STATE_SIZE": S, "CONTROL_SIZE": C, "KNOT_POINTS": K, "knots_per_gpu": K // world,
                           "max_iters": MAX_ITERS, "exit_tol": 0.0, "transport": transport, "transport_fallback_reason": why,
                           "mirror_memory": {0: "uncached", 1: "fine-grained", 2: "hipMalloc"}.get(mem_kind),
                           "pcg_workgroups_per_gpu": groups, "pcg_threads": threads, "semi_resident": bool(semi),
+                          "step": "sharded assembly + persistent launch (100 iterations) + dz on the rank's knots: one library call per rank; "
+                                  "then one all-gather of the lambda / dz rows" if transport == "xgmi" else "replicated assembly + sharded PCG + dz",
                           "parallelism": (f"knot-sharded x{world}; xgmi: one persistent launch per GPU, 2 in-kernel exchanges per iteration "
-                                          "(rank totals to every peer, edge blocks to the neighbours, peer stores into IPC-mapped mirrors)"
+                                          "(rank totals to every peer, edge blocks to the neighbours, peer stores into IPC-mapped mirrors); "
+                                          "single_reduction: 1 exchange per iteration"
                                           if transport == "xgmi" else
                                           f"knot-sharded x{world}; rccl: 2 launches + 2 RCCL all-gathers of (2S+1) scalars per iteration"),
                           "one_gpu_rehearsal": ONE_GPU},
                "pcg_us_per_iter": pcg_us,
+               "out_of_loop_ms": (ms_step - pcg_us * MAX_ITERS * 1e-3) if pcg_us else None,
                "roofline": {"bound": "hbm", "achieved": b_iter * val / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
                             "frac": b_iter * val / 1e9 / (8000.0 * world), "traffic": None,
                             "kernel": "pcg_resident (cluster launch)" if transport == "xgmi" else "stream_step + all-gathers",
-                            "note": "whole sharded step incl. replicated assembly and dz"},
+                            "note": "whole sharded step incl. assembly, dz and the gather of the outputs"},
                "parity": parity}
-    if cl is not None:
-        cl.close()
-    sol.close()
+        out.update(extra)
+    if state is not None:
+        close_state(state)
+    elif sol is not None:
+        sol.close()
     return out
 
 
@@ -335,7 +350,8 @@ def rider_in_child(dist, rank, world, rider, steps, warmup, deadline):
     return res
 
 
-RIDER_KEYS = ("value", "unit", "ms_per_step", "scaling", "dtype", "config", "pcg_us_per_iter", "roofline", "parity")
+RIDER_KEYS = ("value", "unit", "ms_per_step", "scaling", "dtype", "config", "pcg_us_per_iter", "out_of_loop_ms", "roofline", "parity",
+              "ms_per_step_outputs_sharded", "flat_exchange", "single_reduction")
 # the knot-sharded solves that ride along with the replicas line: configs[3] (K = 4096 over the ranks), configs[4]
 # (32/16/1024, "1 vs 8 GPUs") and the size where sharding can pay
 DEFAULT_RIDERS = ("sharded_k4096_f32", "sharded_s32_k1024_f32", "sharded_k262144_f32")
@@ -371,21 +387,38 @@ def rider_summary(r):
             "lam_rel_err_vs_one_gpu": par.get("lam_rel_err_vs_single_gpu"), "iters": par.get("iters")}
 
 
-def attach_riders(out, riders):
-    """Put the sharded results into `config` of the replicas line, flat keys first (configs[3])."""
-    cfg = out["config"]
-    cfg["sharded"] = {name: rider_summary(r) for name, r in riders.items()}
-    k4 = cfg["sharded"].get("sharded_k4096_f32", {})
-    cfg["transport"] = k4.get("transport")
-    cfg["sharded_k4096_us_per_iter"] = k4.get("us_per_iter")
-    cfg["same_system_one_gpu_us_per_iter"] = k4.get("one_gpu_us_per_iter")
-    cfg["sharded_k4096_speedup_vs_one_gpu"] = k4.get("speedup_vs_one_gpu")
-    # TOP-LEVEL (VERDICT r3 #5): `value` of this line is N replicas of the K = 50 workload ("scaling": "weak") and reads ~N x
-    # on any node; the STRONG-scaling answer for BASELINE configs[3] - one K = 4096 system sharded over the N GPUs against
-    # the same system on one GPU - stands beside it under a key of its own so that nobody mistakes one for the other
-    # (null when the rider did not deliver; the expectation per N is tabulated in BASELINE.md section 5)
-    out["sharded_speedup"] = k4.get("speedup_vs_one_gpu")
-    out["sharded_speedup_workload"] = "sharded_k4096_f32 (strong scaling: one 14/7/4096 system over the ranks vs the same system on one GPU)"
+LEAD = "sharded_k4096_f32"           # BASELINE configs[3]: the largest BASELINE system that shards - what --gpus N leads with
+
+
+def attach_riders(rep, riders):
+    """The last line of `bench.py --gpus N`: LED BY THE SHARDED SYSTEM - `value` = PCG iterations/s of ONE
+    14/7/4096 system (BASELINE configs[3]) knot-sharded over the N GPUs, whole steps, "scaling": "strong" - with the same
+    system on ONE GPU beside it (`one_gpu_value`, `sharded_speedup`), so that a SCALE record answers north_star's question
+    directly.  The N replicas of the N = 1 workload (configs[1], K = 50: does not shard, reads ~N x on any node) ride along
+    under `replicas`, the other sharded shapes under `config.sharded`.  If the lead rider did not deliver (its child job
+    faulted, hung or was refused), the replicas line is the headline, unchanged, with the reason."""
+    lead = riders.get(LEAD)
+    summaries = {name: rider_summary(r) for name, r in riders.items()}
+    k4 = summaries.get(LEAD, {})
+    if not isinstance(lead, dict) or "error" in lead or "value" not in lead:
+        out = rep
+        out["config"]["sharded"] = summaries
+        out["sharded_speedup"] = None
+        out["lead_error"] = f"{LEAD} did not deliver: the replicas value leads instead"
+        return out
+    out = {"metric": "PCG iterations/s", "value": lead["value"], "unit": "iterations/s", "n_gpus": rep["n_gpus"],
+           "steps": rep["steps"], "warmup": rep["warmup"], "ms_per_step": lead["ms_per_step"], "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": lead["dtype"], "data": "synthetic", "config": dict(lead["config"]),
+           "roofline": lead.get("roofline"), "pcg_us_per_iter": lead.get("pcg_us_per_iter"), "out_of_loop_ms": lead.get("out_of_loop_ms"),
+           "one_gpu_value": k4.get("one_gpu_iters_per_s"), "one_gpu_us_per_iter": k4.get("one_gpu_us_per_iter"),
+           "sharded_speedup": k4.get("speedup_vs_one_gpu"),
+           "sharded_speedup_workload": f"{LEAD} (strong scaling: one 14/7/4096 system over the ranks vs the same system on one GPU)",
+           "single_reduction": lead.get("single_reduction"),
+           "replicas": {"value": rep["value"], "unit": rep["unit"], "scaling": "weak", "ms_per_step": rep["ms_per_step"],
+                        "workload": rep["config"]["workload"], "roofline_frac": (rep.get("roofline") or {}).get("frac"),
+                        "note": "N independent configs[1] systems, one per GPU, no data-path collective (that shape does not shard)"}}
+    out["config"]["sharded"] = {n_: v for n_, v in summaries.items() if n_ != LEAD}
+    out["config"]["lam_rel_err_vs_one_gpu"] = k4.get("lam_rel_err_vs_one_gpu")
     return out
 
 
@@ -410,7 +443,7 @@ def main(args):
         out = sharded_leg(args, torch, dist, rank, local, world, wl, args.steps, args.warmup)
         if rider_out and rank == 0:
             with open(rider_out + ".tmp", "w") as f:
-                f.write(dumps_strict({k: out[k] for k in RIDER_KEYS}))
+                f.write(dumps_strict({k: out.get(k) for k in RIDER_KEYS}))
             os.replace(rider_out + ".tmp", rider_out)
             out = None
     else:
@@ -420,30 +453,31 @@ def main(args):
         inproc = os.environ.get("GATO_BENCH_RIDERS_INPROC") == "1" or (ONE_GPU and world > 3)
         if rank == 0:
             # the replicas line NOW, before any rider starts: if the riders together outlast the caller's own limit, the last
-            # complete JSON line on stdout is still a valid headline (the final line below repeats it with the riders attached)
+            # complete JSON line on stdout is still a valid line (the final line below is led by the sharded system)
             print(dumps_strict(out, LINE_LIMIT), flush=True)
         riders = {}
         for rider in DEFAULT_RIDERS:
             if rider == "sharded_k262144_f32" and world < 2:
                 continue                                          # one GPU runs it through the streaming kernels: not a sharding number
             big = rider == "sharded_k262144_f32"
-            st, wu = (3, 1) if big else (min(args.steps, 20), min(args.warmup, 3))
+            # the LEAD rider is the line's `value`: exactly the K steps / W warm-up steps the caller asked for
+            st, wu = (3, 1) if big else ((args.steps, args.warmup) if rider == LEAD else (min(args.steps, 20), min(args.warmup, 3)))
             if not inproc:
-                res = rider_in_child(dist, rank, world, rider, st, wu, RIDER_DEADLINE_S * (1.5 if big else 1.0))
+                res = rider_in_child(dist, rank, world, rider, st, wu, RIDER_DEADLINE_S * (1.5 if big or rider == LEAD else 1.0))
                 if rank == 0:
                     riders[rider] = res
                 continue
             try:        # the line above must survive whatever happens in a rider (an error raised on every rank alike)
                 sh = sharded_leg(args, torch, dist, rank, local, world, rider, st, wu)
                 if rank == 0:
-                    riders[rider] = {k: sh[k] for k in RIDER_KEYS}
+                    riders[rider] = {k: sh.get(k) for k in RIDER_KEYS}
             except Exception as e:   # noqa: BLE001
                 if rank == 0:
                     riders[rider] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if rank == 0:
-            attach_riders(out, riders)
             for name, r in riders.items():                        # the full rider objects: EARLIER stdout lines, never the last
                 print(dumps_strict({"rider": name, "result": r}), flush=True)
+            out = attach_riders(out, riders)
     if rank == 0 and out is not None:
         print(dumps_strict(out, LINE_LIMIT), flush=True)
     dist.destroy_process_group()

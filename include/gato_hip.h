@@ -238,7 +238,15 @@ int gato_shard_pcg_done(gato_solver *s, int *done, void *stream);
  *                         afterwards every rank must pass a host barrier before the first gato_cluster_pcg
  *   gato_cluster_pcg      this rank's part of one solve: full-system S / Pinv / gamma / lambda arrays, of which only
  *                         the rows of the rank's range are read / written; same exit_tol and max_iters on every
- *                         rank; asynchronous; d_iters as gato_pcg (-1: a hand-off timed out, on every rank alike) */
+ *                         rank; asynchronous; d_iters as gato_pcg (-1: a hand-off timed out, on every rank alike).
+ *                         Option pcg_variant = 1 on EVERY rank: the single-reduction recurrence - ONE cross-GPU exchange per
+ *                         iteration instead of the reference's two reductions (gato_pcg.cuh:353-394); the ranks then also
+ *                         read Pinv on the knots k0-1, k1 and gamma on k0-2..k1+1.  On return lambda also holds the right
+ *                         neighbour's first block at row k1 (it arrives inside the launch): what dz of knot k1-1 needs
+ *                         (gato_schur.cuh:833-838)
+ *   gato_cluster_linsys   this rank's part of a WHOLE solve (gato_linsys, gpu_library.cu:25-83): stage kernels on the knots
+ *                         its shard reads, gato_cluster_pcg, dz on its range - nothing crosses the host or a collective in
+ *                         between; inputs replicated, d_lambda / d_dz full-length arrays of which the rank's rows are written */
 int gato_cluster_knot_range(int K, int rank, int nranks, int *k0, int *k1);
 int gato_cluster_create(gato_solver *s, int rank, int nranks, void *ipc_handle_out);
 void *gato_cluster_local_mirror(gato_solver *s);
@@ -248,6 +256,9 @@ int gato_cluster_connect(gato_solver *s, const void *ipc_handles, void *const *p
 int gato_cluster_fits(gato_solver *s, int *groups, int *threads);
 int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
                      double exit_tol, int max_iters, int *d_iters, void *stream);
+int gato_cluster_linsys(gato_solver *s, const int *d_G_row, const int *d_G_col, const void *d_G_val, const int *d_C_row,
+                        const int *d_C_col, const void *d_C_val, const void *d_g, const void *d_c, double exit_tol,
+                        int max_iters, double rho, void *d_lambda, void *d_dz, int *d_iters, void *stream);
 int gato_cluster_destroy(gato_solver *s);
 
 /* ---- direct block input (new): the caller already holds the per-knot blocks in the

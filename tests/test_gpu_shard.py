@@ -71,22 +71,25 @@ def test_bench_batched_leg_world1():
 
 
 def test_bench_default_multi_gpu_line_world1():
-    """What `bench.py --gpus N` prints for N > 1 (one system per rank + the sharded solve riding along), with one rank."""
+    """What `bench.py --gpus N` prints for N > 1, with one rank: the last line is led by the knot-sharded configs[3] system
+    (strong scaling), the replicas of the N = 1 workload and the other sharded shapes ride along."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29535", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "replicas",
                         "--steps", "5", "--warmup", "2"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
-    assert d["scaling"] == "weak" and d["n_gpus"] == 1 and d["value"] > 1e5 and d["dtype"] == "f64"
-    assert d["config"]["workload"] == "iiwa_14_7_k50_f64" and 0 < d["roofline"]["frac"] < 1
-    # the LAST line is the compact headline (< 4 KB, strict JSON) with the sharded riders' strong-scaling numbers in config;
-    # the full rider objects are earlier lines
-    last = r.stdout.strip().splitlines()[-1]
+    lines = r.stdout.strip().splitlines()
+    last = lines[-1]
+    d = json.loads(last)
     assert len(last) < 4096
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["value"] > 1e4 and d["dtype"] == "f32" and d["steps"] == 5 and d["warmup"] == 2
     cfg = d["config"]
-    sh = cfg["sharded"]["sharded_k4096_f32"]
-    assert sh["iters_per_s"] > 0 and sh["transport"] in ("xgmi", "rccl") and cfg["transport"] == sh["transport"]
-    assert sh["one_gpu_us_per_iter"] > 0 and sh["lam_rel_err_vs_one_gpu"] < 1e-3 and sh["iters"] == 100
+    assert cfg["workload"] == "sharded_k4096_f32" and cfg["transport"] in ("xgmi", "rccl") and cfg["lam_rel_err_vs_one_gpu"] < 1e-3
+    assert d["one_gpu_value"] > 0 and d["sharded_speedup"] > 0 and d["pcg_us_per_iter"] > 0
+    rep = d["replicas"]
+    assert rep["scaling"] == "weak" and rep["value"] > 1e5 and rep["workload"] == "iiwa_14_7_k50_f64" and 0 < rep["roofline_frac"] < 1
     assert cfg["sharded"]["sharded_s32_k1024_f32"]["iters_per_s"] > 0                     # configs[4] rides along too
-    full = [json.loads(x) for x in r.stdout.strip().splitlines()[:-1] if x.startswith('{"rider"')]
-    assert {x["rider"] for x in full} == set(cfg["sharded"]) and all(x["result"]["scaling"] == "strong" for x in full)
+    # earlier lines: the replicas line on its own (a valid headline should the riders outlast the caller) and the full riders
+    first = json.loads([x for x in lines if x.startswith('{"metric"')][0])
+    assert first["scaling"] == "weak" and first["config"]["workload"] == "iiwa_14_7_k50_f64"
+    full = [json.loads(x) for x in lines[:-1] if x.startswith('{"rider"')]
+    assert {x["rider"] for x in full} == set(cfg["sharded"]) | {"sharded_k4096_f32"} and all(x["result"]["scaling"] == "strong" for x in full)
