@@ -481,12 +481,6 @@ def run_sweep(args, torch, emit):
         annotate(r, other + "_single_reduction_variant")
         r["workload"] += "_single_reduction_variant"
         emit(r)
-    # opt-in pipelined variant (Ghysels-Vanroose: the all-to-all of the dots travels while the two products run)
-    for other in ("iiwa_14_7_k512_f32", "iiwa_14_7_k4096_f32", "iiwa_14_7_k4096_f64", "s32_c16_k1024_f32"):
-        r = aux(other, variant=2)
-        annotate(r, other + "_pipelined_variant")
-        r["workload"] += "_pipelined_variant"
-        emit(r)
     # SURVEY.md 8d run 3: the K=512 system through the STREAMING kernels (matrices re-read every iteration; they fit L2,
     # so the PMC passes show how little of that reaches HBM) beside the register-resident entry above
     r = aux("iiwa_14_7_k512_f32", pcg_mode=2)

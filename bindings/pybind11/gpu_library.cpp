@@ -36,6 +36,10 @@ template <typename T> struct Packed {
     Packed &operator=(const Packed &) = delete;
 };
 
+// side channel (extra information never changes the returned tuple): what the most recent call printed, as data
+static int g_last_iters = -1, g_last_S = 0, g_last_C = 0, g_last_K = 0;
+static std::vector<float> g_last_ms;
+
 static py::tuple main_call(py::object sG_indptr, py::object sG_indices, py::object sG_data, py::object sC_indptr,
                            py::object sC_indices, py::object sC_data, py::object g_, py::object c_, py::object input_lambda_,
                            int testiters, float exit_tol, int max_iters, bool warm_start, float rho)
@@ -59,6 +63,7 @@ static py::tuple main_call(py::object sG_indptr, py::object sG_indices, py::obje
     }
     if (rc == GATO_EINVAL || rc == GATO_ESHAPE) throw py::value_error(gato_last_error());
     if (rc) throw std::runtime_error(gato_last_error());
+    g_last_iters = iters; g_last_S = S; g_last_C = C; g_last_K = K; g_last_ms = ms;
     const char *verbose = getenv("GATO_VERBOSE");
     if (!verbose || verbose[0] != '0') {
         float sum = 0;
@@ -75,4 +80,13 @@ static py::tuple main_call(py::object sG_indptr, py::object sG_indices, py::obje
 PYBIND11_MODULE(gpu_library, m)
 {
     m.def("linsys_solve", &main_call, py::return_value_policy::move);
+    // not in the reference (it only prints the count, gpu_library.cu:190): iterations of the FIRST repeat and the time of every
+    // repeat of the most recent call, as gpu_library.py's last_stats() of the ctypes drop-in
+    m.def("last_stats", []() {
+        py::dict d;
+        py::list ms;
+        for (float t : g_last_ms) ms.append(t);
+        d["iters"] = g_last_iters; d["ms"] = ms; d["S"] = g_last_S; d["C"] = g_last_C; d["K"] = g_last_K; d["precision"] = "f32";
+        return d;
+    });
 }

@@ -740,236 +740,10 @@ __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStr
     }
 }
 
-// ---- A1 + A2 + A3 for MANY knots: one workgroup per CHUNK of consecutive knots, one wavefront per knot --------------
-// The stage path (gather / Schur / stair launches) writes Q^-1, A|B, phi and theta^-1 to HBM and reads them back in the next
-// launch: 985 MB for a batch of 25 600 knots whose inputs and outputs are 421 MB, and every launch is a
-// round of latency-bound one-wave workgroups.  Here a workgroup walks its chunk [k0, k1) in rounds of NW knots (wave w takes
-// knot kr + w) and everything one knot hands to the next stays in LDS: per knot one SLOT with Q^-1, R^-1, [A | B], phi,
-// theta^-1 and a temporary; NW + 1 slots, slot(k) = (k - kb) mod (NW + 1), so the previous round's last knot is still there
-// when the next round needs it.  A round is gather -> invert | barrier | Schur (needs slot(k-1)) -> theta^-1 | barrier |
-// stair between k-1 and k (needs theta^-1 of both) | barrier.  A chunk that does not start at knot 0 first re-derives
-// theta^-1 of knot k0-1 from the blocks of knots k0-2, k0-1 (two halo knots: gathered and inverted, one Schur step, nothing
-// written) - with one chunk per system, as in batches of K = 50, there is no halo at all.
-// Per block the instruction sequences are those of gather_kernel / schur_kernel / ss_kernel (same device functions, same
-// operand order), so every work buffer is bit-identical to the stage path.
-// MEASURED (MI355X, round 3, tools/asm_modes.py): the launch moves less than half the bytes of the stage path and takes the
-// SAME time - 512 x 14/7/50 f64: 270 us against 272 (f32 141 / 145), 14/7/4096 f32 42 / 41, f64 65 / 55, 32/16/1024 f32 209 /
-// 78 - because neither is bound by bytes: a knot is ~3 000 dependent wave-instructions (three Gauss-Jordan eliminations on 28
-// of 64 lanes, bisections, 28 MFMA steps) and what counts is how many knots a SIMD has in flight; the stage launches keep
-// 4-5 one-wave workgroups per SIMD busy, a chunk's waves wait for each other at three barriers per round.  Smaller chunks
-// (more workgroups, two halo knots each) are slower still (8 knots: 365 us).  Not selected automatically (option asm_mode = 3).
-template <typename T, int S, int C>
-struct ChunkSlot {                               // element offsets inside one knot's slot
-    static constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C;
-    static constexpr int QI = 0;                 // Q_k, then Q_k^-1 in place
-    static constexpr int RI = QI + SS;           // R_k, then R_k^-1
-    static constexpr int AB = RI + CC;           // [A_k | B_k]  (contiguous with QI, RI: zeroed together)
-    static constexpr int PHI = AB + SS + SC;     // phi_k
-    static constexpr int TH = PHI + SS;          // theta_k, then Pinv[k].main = -theta_k^-1 in place
-    static constexpr int TMP = TH + SS;          // BR_k during the Schur step, then the stair products
-    static constexpr int VQ = TMP + SS;          // q_k, r_k
-    static constexpr int VV = VQ + n;            // 3 x S scratch of the gamma terms
-    static constexpr int ELEMS = (VV + 3 * S + 3) / 4 * 4;
-    static constexpr int PTRS = (n + 1) + (S + 1);                 // row pointers of the knot's G rows and C row-block (ints)
-};
-
-// LDS hand-over inside ONE wave (a lane reads what another lane of the same wave wrote): the wave's LDS operations execute
-// in order, so all that is needed is that the compiler keeps them in order too.
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-// Workgroup barrier that waits for this wave's LDS operations only: __syncthreads() would also drain its global stores
-// (vmcnt(0)), and the waves of the chunked launch have their output blocks in flight at every barrier.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <typename T, int S, int C, int NW>
-__global__ __launch_bounds__(NW * WAVE) void assemble_chunk_kernel(AsmArgs a, int K, int chunk, BatchStride bs)
-{
-    typedef ChunkSlot<T, S, C> L;
-    constexpr int n = S + C, SS = S * S, CC = C * C, SC = S * C, ABS = SS + SC, NSLOT = NW + 1;
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    T *lds = (T *)lds_raw;
-    int *ptrs = (int *)(lds + (size_t)NSLOT * L::ELEMS);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sys = blockIdx.y;
-    const T *g = (const T *)a.g + sys * bs.n, *c = (const T *)a.c + sys * bs.sk;
-    T *Gd = (T *)a.Gd + sys * bs.g, *Cd = (T *)a.Cd + sys * bs.c, *Ginv = (T *)a.Ginv + sys * bs.g;
-    T *Sbd = (T *)a.Sbd + sys * bs.bd, *Pbd = (T *)a.Pbd + sys * bs.bd, *gamma = (T *)a.gamma + sys * bs.sk;
-    const T *G_val = (const T *)a.G_val + sys * (a.mode == 0 ? bs.nnzG : bs.g), *C_val = (const T *)a.C_val + sys * bs.nnzC;
-    const T rho = (T)a.rho;
-    const int k0 = blockIdx.x * chunk, k1 = min(K, k0 + chunk);
-    const int kb = max(0, k0 - 2);                                           // first knot touched (halo)
-    int *sPtrG = ptrs + wave * L::PTRS, *sPtrC = sPtrG + (n + 1);
-    auto slot = [&](int k) -> T * { return lds + (size_t)((k - kb) % NSLOT) * L::ELEMS; };
-
-    for (int kr = kb; kr < k1; kr += NW) {
-        const int k = kr + wave;
-        const bool on = k < k1, own = on && k >= k0;                         // halo knots: computed, never written
-        const bool first = k == 0, last = k == K - 1;
-        T *sl = slot(on ? k : kb), *sQ = sl + L::QI, *sR = sl + L::RI, *sAB = sl + L::AB, *sPhi = sl + L::PHI, *sTh = sl + L::TH;
-        T *sTmp = sl + L::TMP, *sq = sl + L::VQ, *sv = sl + L::VV;
-        const size_t gk = (size_t)k * (SS + CC);
-        T *Sk = Sbd + (size_t)k * 3 * SS, *Pk = Pbd + (size_t)k * 3 * SS;
-        // ---- 1. this knot's blocks into its slot (gather_kernel's scatter, entry-parallel over the wave) ----
-        if (on) {
-            if (a.mode == 0) {
-                const int r0 = k * n, nrG = last ? S : n;
-                const int c0 = (k + 1) * S, nrC = last ? 0 : S;
-                for (int i = lane; i <= nrG; i += WAVE) sPtrG[i] = a.G_row[r0 + i];
-                if (nrC) for (int i = lane; i <= nrC; i += WAVE) sPtrC[i] = a.C_row[c0 + i];
-                for (int i = lane; i < SS + CC + ABS; i += WAVE) sQ[i] = (T)0;        // QI, RI, AB are contiguous
-                wave_lds_sync();
-                const int eG0 = sPtrG[0], nG = sPtrG[nrG] - eG0;
-                const int eC0 = nrC ? sPtrC[0] : 0, nC = nrC ? sPtrC[nrC] - eC0 : 0;
-                constexpr int U = 4;
-                for (int t0 = lane; t0 < nG + nC; t0 += WAVE * U) {
-                    int col[U];
-                    T val[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int t = t0 + u * WAVE;
-                        if (t < nG) { col[u] = a.G_col[eG0 + t]; val[u] = G_val[eG0 + t]; }
-                        else if (t < nG + nC) { col[u] = a.C_col[eC0 + (t - nG)]; val[u] = C_val[eC0 + (t - nG)]; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int t = t0 + u * WAVE;
-                        if (t < nG) {                                          // csr_to_custom_G, gato_schur.cuh:674-704
-                            const int isr = row_of_entry(sPtrG, nrG, eG0 + t);
-                            const int isc = col[u] % n;
-                            const T v = val[u] + (col[u] == r0 + isr ? rho : (T)0);
-                            if (isc < S) { if (isr < S) sQ[isc * S + isr] = v; }
-                            else if (isr >= S) sR[(isc - S) * C + (isr - S)] = v;
-                        } else if (t < nG + nC) {                              // csr_to_custom_C, :707-743
-                            const int i = row_of_entry(sPtrC, nrC, eC0 + (t - nG));
-                            if (col[u] / n <= k) sAB[(col[u] % n) * S + i] = val[u];
-                        }
-                    }
-                }
-            } else {                                                           // blocks handed over (mode 2: + rho; mode 1: as they are)
-                const T *Gin = a.mode == 2 ? G_val : Gd;
-                const T r2 = a.mode == 2 ? rho : (T)0;
-                for (int i = lane; i < SS; i += WAVE) sQ[i] = Gin[gk + i] + ((i % (S + 1) == 0) ? r2 : (T)0);
-                if (!last) {
-                    for (int i = lane; i < CC; i += WAVE) sR[i] = Gin[gk + SS + i] + ((i % (C + 1) == 0) ? r2 : (T)0);
-                    copy_in(sAB, Cd + (size_t)k * ABS, ABS, lane);
-                }
-            }
-            for (int i = lane; i < (last ? S : n); i += WAVE) sq[i] = g[(size_t)k * n + i];      // q_k, r_k
-        }
-        wave_lds_sync();
-        if (on) {
-            if (own && a.mode != 1) {                                          // the knot's dense blocks, written once
-                for (int i = lane; i < SS + (last ? 0 : CC); i += WAVE) Gd[gk + i] = sQ[i];
-                if (a.mode == 0 && !last) for (int i = lane; i < ABS; i += WAVE) Cd[(size_t)k * ABS + i] = sAB[i];
-            }
-            if (first) {                                                       // Pinv[0].main = -Q_0 (:75-81): also the left neighbour's theta^-1 of knot 1
-                for (int i = lane; i < SS; i += WAVE) {
-                    const T v = -sQ[i];
-                    sTh[i] = v;
-                    if (own) Pk[SS + i] = v;
-                }
-            }
-            // ---- 2. Q_k^-1, R_k^-1 in place (register Gauss-Jordan, invert_G_kernel's arithmetic) ----
-            wave_lds_sync();
-            invert_to<T, S>(sQ, sQ, lane, (T)1);
-            if (!last) invert_to<T, C>(sR, sR, lane, (T)1);
-            wave_lds_sync();
-            if (own) {
-                for (int i = lane; i < SS + (last ? 0 : CC); i += WAVE) Ginv[gk + i] = sQ[i];
-            }
-        }
-        lds_barrier();
-        // ---- 3. Schur step of knot k: needs slot(k-1) (schur_kernel's sequence, operands in LDS) ----
-        if (on && first) {                                                     // :26-147
-            mv<T, S, S>(sv, sQ, sq, lane);
-            if (own) {
-                for (int i = lane; i < SS; i += WAVE) {
-                    Sk[i] = (T)0;                                              // S[0].left: unused (:157-165)
-                    Sk[SS + i] = -sQ[i];                                       // :120-126
-                    Pk[i] = (T)0;
-                    if (last) { Pk[2 * SS + i] = (T)0; Sk[2 * SS + i] = (T)0; }
-                }
-            }
-            wave_lds_sync();
-            if (own) for (int i = lane; i < S; i += WAVE) gamma[i] = c[i] - sv[i];                 // :131-146, + c_0 (D4)
-        } else if (on && k > kb) {
-            const T *pm = slot(k - 1);
-            const T *sA = pm + L::AB, *sB = sA + SS, *sQim = pm + L::QI, *sRim = pm + L::RI, *sqm = pm + L::VQ;
-            T *sBR = sTmp;
-            // phi = A Q_{k-1}^-1 (:277-285), BR = B R_{k-1}^-1 (:293-301)
-            mfma_for_tiles<T, S, S>(lane,
-                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sA, sQim, mt, nt, lane, acc); },
-                [&](int r, int cc, T v) {
-                    sPhi[cc * S + r] = v;
-                    if (own) {
-                        Sk[cc * S + r] = -v;                                   // S[k].left = -phi      :388-394
-                        Sk[2 * SS - 3 * SS + r * S + cc] = -v;                 // S[k-1].right = -phi^T :443-455
-                    }
-                });
-            mfma_for_tiles<T, S, C>(lane,
-                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, C, C, false>(sB, sRim, mt, nt, lane, acc); },
-                [&](int r, int cc, T v) { sBR[cc * S + r] = v; });
-            mv<T, S, S>(sv, sQ, sq, lane);                                     // Q_k^-1 q_k           :306-310
-            wave_lds_sync();
-            mv<T, S, S>(sv + S, sPhi, sqm, lane);                              // phi q_{k-1}          :316-320
-            mv<T, S, C>(sv + 2 * S, sBR, sqm + S, lane);                       // BR r_{k-1}           :324-328
-            // theta = phi A^T + Q_k^-1 + BR B^T (:342-384)
-            mfma_for_tiles<T, S, S>(lane,
-                [&](int mt, int nt, typename Mfma<T>::acc_t acc) {
-                    acc = mfma_tile<T, S, S, S, true>(sPhi, sA, mt, nt, lane, acc);
-                    return mfma_tile<T, S, C, S, true>(sBR, sB, mt, nt, lane, acc);
-                },
-                [&](int r, int cc, T v) {
-                    const T th = v + sQ[cc * S + r];
-                    sTh[cc * S + r] = th;
-                    if (own) Sk[SS + cc * S + r] = -th;                        // S[k].main   :398-404
-                });
-            wave_lds_sync();
-            if (own) {
-                for (int i = lane; i < S; i += WAVE) {
-                    T gt = sv[i] - c[(size_t)k * S + i];                       // :311-313
-                    gt += sv[2 * S + i] + sv[S + i];                           // :336-338
-                    gamma[(size_t)k * S + i] = -gt;                            // :435-438
-                }
-                if (last)
-                    for (int i = lane; i < SS; i += WAVE) {
-                        Pk[2 * SS + i] = (T)0;
-                        Sk[2 * SS + i] = (T)0;                                 // last right: unused (:166-174)
-                    }
-            }
-            invert_to<T, S>(sTh, sTh, lane, (T)-1);                            // Pinv[k].main = -theta^-1  :407-422
-            wave_lds_sync();
-            if (own) for (int i = lane; i < SS; i += WAVE) Pk[SS + i] = sTh[i];
-        }
-        lds_barrier();
-        // ---- 4. symmetric stair between knots k-1 and k (ss_kernel / assemble_kernel; S[k].left = -phi) ----
-        if (own && !first) {
-            const T *sThm = slot(k - 1) + L::TH;
-            mfma_for_tiles<T, S, S>(lane,                                      // Pinv[k].main * phi
-                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sTh, sPhi, mt, nt, lane, acc); },
-                [&](int r, int cc, T v) { sTmp[cc * S + r] = v; });
-            wave_lds_sync();
-            mfma_for_tiles<T, S, S>(lane,                                      // Pinv[k].left          :578-611
-                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sTmp, sThm, mt, nt, lane, acc); },
-                [&](int r, int cc, T v) { Pk[cc * S + r] = v; });
-            wave_lds_sync();
-            mfma_for_tiles<T, S, S>(lane,                                      // Pinv[k-1].main * phi^T
-                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, true>(sThm, sPhi, mt, nt, lane, acc); },
-                [&](int r, int cc, T v) { sTmp[cc * S + r] = v; });
-            wave_lds_sync();
-            mfma_for_tiles<T, S, S>(lane,                                      // Pinv[k-1].right       :614-648 (D1)
-                [&](int mt, int nt, typename Mfma<T>::acc_t acc) { return mfma_tile<T, S, S, S, false>(sTmp, sTh, mt, nt, lane, acc); },
-                [&](int r, int cc, T v) { Pk[2 * SS - 3 * SS + cc * S + r] = v; });
-        }
-        lds_barrier();
-    }
-}
+// (Rounds 3-4 also had a CHUNKED fused launch here - one workgroup per chunk of consecutive knots, everything between the stages in
+// LDS, option asm_mode = 3.  It moved less than half the bytes of the stage path and took the SAME time on every shape measured
+// (512 x 14/7/50 f64: 270 us against 272, 14/7/4096 f32 42 / 41, 32/16/1024 f32 209 / 78): neither is bound by bytes but by how
+// many knots a SIMD has in flight.  Removed in round 5; DESIGN_LOG.md 3.3 keeps the numbers.)
 
 // ---- A9: dz back-substitution (gato_schur.cuh:758-867) -------------------------------------------
 template <typename T, int S, int C>
@@ -1069,39 +843,9 @@ int launch_form_schur(const Dims &d, const T *Gd, const T *Cd, const T *g, const
     return GATO_OK;
 }
 
-template <typename T, int S, int C, int NW>
-static int launch_assemble_chunked(const Dims &d, const AsmArgs &a, hipStream_t st)
-{
-    typedef ChunkSlot<T, S, C> L;
-    constexpr size_t BYTES = sizeof(T) * (size_t)(NW + 1) * L::ELEMS + sizeof(int) * (size_t)NW * L::PTRS;
-    static_assert(BYTES <= 160 * 1024, "chunk slots must fit the LDS of a CU");
-    if (BYTES > 48 * 1024) {
-        static bool attr_set[64] = {};
-        int dev = 0;
-        GATO_HIP_CHECK(hipGetDevice(&dev));
-        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            GATO_HIP_CHECK(hipFuncSetAttribute((const void *)assemble_chunk_kernel<T, S, C, NW>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)BYTES));
-            if (dev >= 0 && dev < 64) attr_set[dev] = true;
-        }
-    }
-    const int chunk = a.chunk < 1 ? 1 : a.chunk;
-    const int gx = (d.K + chunk - 1) / chunk;
-    hipLaunchKernelGGL((assemble_chunk_kernel<T, S, C, NW>), dim3(gx, d.B), dim3(NW * WAVE), BYTES, st, a, d.K, chunk, batch_stride(d));
-    GATO_HIP_CHECK(hipGetLastError());
-    return GATO_OK;
-}
-
-// waves (= knots per round) of the chunked launch: as many as leave two workgroups per CU their LDS
-template <typename T, int S, int C> struct ChunkWaves {
-    static constexpr size_t per = sizeof(T) * ChunkSlot<T, S, C>::ELEMS + sizeof(int) * ChunkSlot<T, S, C>::PTRS;
-    static constexpr int v = 9 * per <= 76 * 1024 ? 8 : (5 * per <= 76 * 1024 ? 4 : (3 * per <= 150 * 1024 ? 2 : 1));
-};
-
 template <typename T, int S, int C>
 int launch_assemble(const Dims &d, const AsmArgs &a, hipStream_t st)
 {
-    if (a.chunk > 0) return launch_assemble_chunked<T, S, C, ChunkWaves<T, S, C>::v>(d, a, st);
     constexpr int NT = 512;
     typedef AsmLds<T, S, C> L;
     if (L::BYTES > 48 * 1024) {                      // beyond the default dynamic-LDS limit: opt in once per device

@@ -144,8 +144,7 @@ struct gato_solver {
     unsigned pcg_epoch;        // next free hand-off epoch (resident kernels)
     int pcg_launch_id;
     size_t slots_bytes;
-    int asm_mode;       // option: 0 = auto, 1 = stage kernels one by one (convert / invert / schur / stair), 2 = fused launch (workgroup per knot), 3 = chunked launch
-    int asm_chunk;      // option: knots per workgroup of the chunked launch (0 = auto)
+    int asm_mode;       // option: 0 = auto, 1 = stage kernels one by one (convert / invert / schur / stair), 2 = fused launch (workgroup per knot)
     int last_asm_fused, stamp_asm, last_image;
     double *eta_hist;   // eta after init and after every iteration (option record_eta), GATO_ETA_HIST_MAX + 1 entries
     int record_eta;
@@ -183,14 +182,11 @@ struct gato_solver {
     int img_ld;
     int img_fresh;                    // the fused assembly launch of the whole solve in progress has just written them
     int no_image;                     // option: the one-workgroup kernels load from S_bd / P_bd as every other kernel
-    int mixed_dense;                  // option: fp64 mixed-rows kernel in round 2's dense layout (A/B against the DPP-row waves)
     int coop_launch;                  // option: multi-workgroup persistent launches through hipLaunchCooperativeKernel
-    int f32_hybrid;                   // option (default 0): fp32 one-workgroup solves of 37..52 knots through the two-row + DPP-row hybrid kernel
     hipEvent_t host_ev[2];            // the host-pointer drop-in's timing events, kept across calls
     int dz_fused;                     // the most recent PCG launch also did the dz back-substitution (1: in the solving workgroup, 2: in helper blocks)
     int *dz_flag;                     // device word for the helper blocks of the one-workgroup fp64 launch
     int no_fuse_dz;                   // option
-    int shared_windows;               // option: one-workgroup kernels with shared operand windows (the four-barrier form)
     unsigned long long **cl_tab;      // device copy of cl.peer (the kernel reads the peers' mirror addresses from it)
 };
 
@@ -482,7 +478,6 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "pcg_threads")) s->pcg_threads = value;
     else if (!strcmp(name, "pcg_groups")) s->pcg_groups = value;
     else if (!strcmp(name, "asm_mode")) s->asm_mode = value;
-    else if (!strcmp(name, "asm_chunk")) s->asm_chunk = value;
     else if (!strcmp(name, "pcg_semi")) s->pcg_semi = value;
     else if (!strcmp(name, "pcg_epoch")) s->pcg_epoch = (unsigned)value;      // test hook: place the counter near its wrap
     else if (!strcmp(name, "stamp_asm")) s->stamp_asm = value;
@@ -500,11 +495,8 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "timeout_ms")) s->timeout_ms = value > 0 ? value : 2000;
     else if (!strcmp(name, "max_workgroups")) s->max_workgroups = value;
     else if (!strcmp(name, "no_fuse_dz")) s->no_fuse_dz = value;
-    else if (!strcmp(name, "shared_windows")) s->shared_windows = value;
     else if (!strcmp(name, "no_image")) s->no_image = value;
-    else if (!strcmp(name, "mixed_dense")) s->mixed_dense = value;
     else if (!strcmp(name, "coop_launch")) s->coop_launch = value;
-    else if (!strcmp(name, "f32_hybrid")) s->f32_hybrid = value;
     else if (!strcmp(name, "cluster_flat")) s->cluster_flat = value;
     else if (!strcmp(name, "knot_lo") || !strcmp(name, "knot_hi")) {          // stage-level entries: knots [knot_lo, knot_hi)
         if (value < 0 || value > s->d.K) { set_error("%s = %d is outside [0, %d]", name, value, s->d.K); return GATO_EINVAL; }
@@ -915,10 +907,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.K = s->d.K; a.max_iters = max_iters; a.exit_tol = exit_tol;
         a.batch = batch;
         a.pair = s->plan_pair;
-        a.shared_windows = s->shared_windows;
-        a.mixed_dense = s->mixed_dense;
         a.coop = s->coop_launch && groups > 1 && batch == 1 && !cg1;      // (the single-reduction kernel keeps the plain launch)
-        a.f32_hybrid = s->f32_hybrid;
         // (every lane of the launch loads rows 2 tid, 2 tid + 1 resp. its own row: all of them must lie inside a column of the image)
         if (s->img_fresh && !s->no_image && batch == 1 && d_S == s->Sbd && d_Pinv == s->Pbd &&
             ((s->plan_pair == 1 && 2 * threads <= s->img_ld) || (s->plan_pair == 2 && s->plan.mixed_rows <= s->img_ld))) {
@@ -960,9 +949,9 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         // (batches only: every system's workgroup does its own dz and a launch of 25 600 one-wave workgroups goes away; for
         //  ONE system the single workgroup is as latency bound as that launch was - measured 11 us in the epilogue against
         //  5.3 us + a launch gap - unless asked for with no_fuse_dz = -1)
-        // (fp32 two-rows-per-lane kernel: its epilogue exists for batches; the opt-in hybrid kernel has none)
+        // (fp32 two-rows-per-lane kernel: its epilogue exists for batches)
         if (s->fz.dz && (s->no_fuse_dz < 0 || (!s->no_fuse_dz && batch > 1)) && groups == 1 && !cg1 &&
-            (s->plan_pair != 1 || (batch > 1 && !s->f32_hybrid)) && !a.semi && !s->stamp_pcg) {
+            (s->plan_pair != 1 || batch > 1) && !a.semi && !s->stamp_pcg) {
             a.dz_Ginv = s->fz.Ginv; a.dz_Cd = s->fz.Cd; a.dz_g = s->fz.g; a.dz = s->fz.dz; a.C = s->d.C;
             s->dz_fused = 1;
         }
@@ -1134,12 +1123,10 @@ static int assemble(gato_solver *s, int mode, const int *G_row, const int *G_col
     // the fused launch always forms the stair blocks: the other preconditioner modes take the stage kernels
     const long long knots = (long long)s->d.K * s->d.B;
     // option asm_mode: 0 auto (2 while one round of workgroups covers the solve, else 1 - measured crossover),
-    // 1 stage kernels, 2 one launch with a workgroup per knot (three-fold recomputation), 3 one launch with a workgroup per
-    // chunk of consecutive knots (everything between the stages stays in LDS)
+    // 1 stage kernels, 2 one launch with a workgroup per knot (three-fold recomputation)
     const bool stair = s->precon_mode == GATO_PRECON_STAIR;
-    const bool chunked = stair && s->asm_mode == 3;          // measured equal to the stage kernels at best (gato_assembly.hip): opt-in
-    const bool fused = chunked || (stair && (s->asm_mode == 2 || (s->asm_mode == 0 && knots <= 2ll * s->num_cus)));
-    s->last_asm_fused = chunked ? 2 : fused;
+    const bool fused = stair && (s->asm_mode == 2 || (s->asm_mode == 0 && knots <= 2ll * s->num_cus));
+    s->last_asm_fused = fused;
     s->img_fresh = 0;
     if (!fused) {
         if (mode == 0) {                 // CSR: the gather launch also inverts Q_k, R_k while they sit in LDS
@@ -1167,22 +1154,9 @@ static int assemble(gato_solver *s, int mode, const int *G_row, const int *G_col
     a.rho = rho; a.g = d_g; a.c = d_c;
     a.Gd = s->G_dense; a.Cd = const_cast<void *>(C_dense); a.Ginv = s->Ginv; a.Sbd = s->Sbd; a.Pbd = s->Pbd; a.gamma = s->gamma;
     a.stamps = s->stamp_asm ? (unsigned long long *)s->sw.scalars + 8 : nullptr;
-    if (!chunked && s->imgS && !s->no_image && s->d.B == 1) {        // the workgroup-per-knot launch also writes the PCG images
+    if (s->imgS && !s->no_image && s->d.B == 1) {        // the workgroup-per-knot launch also writes the PCG images
         a.imgS = s->imgS; a.imgP = s->imgP; a.img_ld = s->img_ld;
         s->img_fresh = 1;
-    }
-    if (chunked) {
-        // knots per workgroup: a whole system where there are many (no halo knots at all); else enough chunks for ~2 workgroups
-        // per CU, at least 8 knots each (a chunk recomputes two halo knots)
-        int ch = s->asm_chunk > 0 ? s->asm_chunk : 0;
-        if (!ch) {
-            if (s->d.B >= 2 * s->num_cus || s->d.K <= 64) ch = s->d.K;
-            else {
-                const long long want = (knots + 2ll * s->num_cus - 1) / (2ll * s->num_cus);
-                ch = (int)(want < 8 ? 8 : want);
-            }
-        }
-        a.chunk = ch > s->d.K ? s->d.K : ch;
     }
     return s->ops->assemble(s->d, a, st);
 }

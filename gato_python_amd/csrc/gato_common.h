@@ -164,7 +164,6 @@ struct PcgLaunch {
     double exit_tol;
     int batch;                   // > 1: blockIdx.x = system index, one workgroup per system (groups must be 1)
     int pair;                    // fp32 one-workgroup kernel with two rows per lane
-    int shared_windows;          // one-workgroup two-rows-per-lane kernels: 1 = shared operand windows (four barriers per iteration) instead of wave-private ones
     int xcd_pack;                // 2..32 workgroups: place them on one XCD (grid 8x oversubscribed, 7 of 8 blocks exit)
     int xcd_sel;                 // 0..7: the XCD (blockIdx % 8) that hosts them
     int wave_pub;                // launches of 2..32 workgroups: every wave publishes its own partial (no gather barrier); 0 = gathered form
@@ -211,9 +210,7 @@ struct PcgLaunch {
     int ablate;                        // diagnostic: timing-only ablation mask (0 in production)
     unsigned long long *stamps;        // optional: diagnostic cycle stamps (16 words), selects the DIAG = 1 build
     int diag;                          // 2: the build with the timing-only switches (ablate) but no stamps
-    int mixed_dense;                   // fp64 one-workgroup mixed-rows kernel: round 2's dense one-row waves instead of DPP rows (A/B)
     int coop;                          // multi-workgroup persistent launches through hipLaunchCooperativeKernel (option coop_launch)
-    int f32_hybrid;                    // fp32 one-workgroup kernel: the hybrid of two-row and DPP-row waves (opt-in: measured equal)
 };
 
 // Cross-GPU mirror of a cluster launch, per epoch parity (granules): one 128-B line per rank for its total (written by
@@ -282,7 +279,6 @@ struct AsmArgs {
     void *imgS, *imgP;               // optional (one system): S and Pinv also as column-major images over ALL rows (PcgLaunch::imgS), leading dimension img_ld
     int img_ld;
     unsigned long long *stamps;      // diagnostic (option stamp_asm): one workgroup's phase boundaries, 100 MHz ticks
-    int chunk;                       // > 0: the chunked launch (assemble_chunk_kernel), this many consecutive knots per workgroup
 };
 template <typename T, int S, int C>
 int launch_assemble(const Dims &d, const AsmArgs &a, hipStream_t st);

@@ -1266,9 +1266,9 @@ __device__ __forceinline__ void one_system_helper(const PcgLaunch &a, T *scratch
 // (IIWA 14/7/50: 6 waves instead of 11), and the one-CU regime extends to K*S <= 2*MAXT rows.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// PW (round 3, what production runs): WAVE-PRIVATE operand windows.  In the shared-window form an iteration has four
+// WAVE-PRIVATE operand windows (round 3; the shared-window form it replaced - option shared_windows - was removed in round 5).  In a shared-window form an iteration has four
 // barriers: two inside the block sums and two between a vector update and the product that reads the updated window (every
-// lane must have stored its entries of r / p before any lane reads its neighbours').  With PW every wave keeps its OWN copy of
+// lane must have stored its entries of r / p before any lane reads its neighbours').  Here every wave keeps its OWN copy of
 // the part of the r and p windows its lanes read - its own 128 rows plus a halo of up to 2S - 1 rows on either side - and
 // advances the halo rows itself: up to 4S - 2 lanes of the wave hold one halo row of r and p in a register, fetch that row's
 // entry of upsilon (of r~) from a shared exchange window which the owners fill BEFORE the block sum's barrier, and apply the
@@ -1277,7 +1277,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // barriers and the LDS write latency in front of them are gone: two barriers per iteration.  14/7/50 fp32: 1.405 -> 1.340 us
 // per iteration (with 14 spilled VGPRs).  The fp64 mixed-rows kernel gains nothing from it (its loop is bound by the LDS read
 // queue, not by barriers: measured 1.945 us with two barriers and no halo update at all against 1.94) and keeps shared windows.
-template <int S, int MAXT, bool PW = false>
+template <int S, int MAXT>
 __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
 {
     constexpr int H = S / 2;                       // lanes per knot
@@ -1285,11 +1285,15 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
     constexpr int MAXK = (MAXT + H - 1) / H;
     static_assert(S % 2 == 0, "two rows per lane need an even STATE_SIZE");
     __shared__ __attribute__((aligned(16))) float xs[2][(MAXK + 2) * SP];
-    __shared__ __attribute__((aligned(16))) float wpart[2][4 * ((MAXT + 63) / 64)];
+    // (partials_total_all8 reads the four row sums of EIGHT waves whatever the launch has: slots of waves that do not exist - MAXT =
+    //  256 for the generic shapes - exist here and hold zeros)
+    constexpr int WPW = (MAXT + 63) / 64 < 8 ? 8 : (MAXT + 63) / 64;
+    __shared__ __attribute__((aligned(32))) float wpart[2][4 * WPW];
+    static_assert(MAXT > 512 || sizeof(wpart) / 2 >= 32 * sizeof(float), "partials_total_all8 reads 32 values per parity");
     constexpr int PK = (128 - 1 + S - 1) / S + 1 + 2;                 // knots a wave's 128 rows can span + a halo knot on either side
-    constexpr int PWLEN = PW ? (MAXT / 64) * PK * SP : 4;
-    static_assert(!PW || 4 * S - 2 <= 64, "private windows: one halo row per lane");
-    __shared__ __attribute__((aligned(16))) float pwin[2][PWLEN];     // PW: [0] = p, [1] = r, wave after wave
+    constexpr int PWLEN = (MAXT / 64) * PK * SP;
+    static_assert(4 * S - 2 <= 64, "private windows: one halo row per lane");
+    __shared__ __attribute__((aligned(16))) float pwin[2][PWLEN];     // [0] = p, [1] = r, wave after wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int K = a.K;
@@ -1331,15 +1335,14 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         }
     }
     for (int i = tid; i < 2 * (MAXK + 2) * SP; i += blockDim.x) (&xs[0][0])[i] = 0.f;
-    for (int i = tid; i < 2 * 4 * ((MAXT + 63) / 64); i += blockDim.x) (&wpart[0][0])[i] = 0.f;       // partials_total_all8 reads all eight waves' slots
-    if constexpr (PW)
-        for (int i = tid; i < 2 * PWLEN; i += blockDim.x) (&pwin[0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * 4 * WPW; i += blockDim.x) (&wpart[0][0])[i] = 0.f;       // partials_total_all8 reads all eight waves' slots
+    for (int i = tid; i < 2 * PWLEN; i += blockDim.x) (&pwin[0][0])[i] = 0.f;
     __syncthreads();
-    // PW: the wave's rows [R0, R1), its private windows (slot 0 = knot jf - 1) and the lane's halo row
+    // the wave's rows [R0, R1), its private windows (slot 0 = knot jf - 1) and the lane's halo row
     int hoff = 0, hpo = 0, own_po = 0, win_po = 0;
     bool hvalid = false;
     float *pw_p = nullptr, *pw_r = nullptr;
-    if constexpr (PW) {
+    {
         const int R0 = 128 * wave, R1 = min(R0 + 128, K * S);
         pw_p = &pwin[0][wave * PK * SP]; pw_r = &pwin[1][wave * PK * SP];
         if (R0 < R1) {
@@ -1392,20 +1395,12 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
 #endif
     };
     unsigned epoch = 0;
-    auto block_sum = [&](float prod) -> float {
-        ++epoch;
-        float *wp = wpart[epoch & 1];
-        partials_store(wp, wave, lane, prod);
-        __syncthreads();
-        if constexpr (MAXT <= 512) return partials_total_all8<float>(wp, lane);
-        return partials_total<float, 16>(wp, nwaves, lane);
-    };
     // (lanes without rows hold zeros in every vector - their matrix rows are zero - and store them into the zero padding in
     //  front of knot 0 instead of sitting out behind an exec mask, as in pcg_single_f64m_kernel)
     const int put_off = active ? (j + 1) * SP + r0 : r0;
     auto put = [&](float *buf, f32x2 v) { *reinterpret_cast<f32x2 *>(buf + put_off) = v; };
 
-    const float *wp_ = PW ? pw_p + win_po : &xs[0][j * SP], *wr_ = PW ? pw_r + win_po : &xs[1][j * SP];
+    const float *wp_ = pw_p + win_po, *wr_ = pw_r + win_po;
     auto put_private = [&](float *pw, f32x2 v, float g) {
         if (active) *reinterpret_cast<f32x2 *>(pw + own_po) = v;
         if (hvalid) pw[hpo] = g;
@@ -1431,68 +1426,43 @@ __global__ __launch_bounds__(MAXT) void pcg_single_f32x2_kernel(PcgLaunch a)
         r -= times_window(sm, &xs[0][j * SP]);
         __syncthreads();
     }
-    float gr = 0.f, gp = 0.f;                                              // PW: r and p of the lane's halo row
-    if constexpr (PW) {
-        put(xs[0], r);
-        __syncthreads();
-        gr = hvalid ? xs[0][hoff] : 0.f;
-        put_private(pw_r, r, gr);
-    } else {
-        put(xs[1], r);
-        __syncthreads();
-    }
+    float gr = 0.f, gp = 0.f;                                              // r and p of the lane's halo row
+    put(xs[0], r);
+    __syncthreads();
+    gr = hvalid ? xs[0][hoff] : 0.f;
+    put_private(pw_r, r, gr);
     f32x2 rt = times_window(pm, wr_);                                      // gato_pcg.cuh:316-335
     float eta, eta_new = 0.f;
-    if constexpr (PW) {
-        put(xs[1], rt);
-        eta = block_sum_x(r[0] * rt[0] + r[1] * rt[1], xs[1], gp);
-    } else eta = block_sum(r[0] * rt[0] + r[1] * rt[1]);
+    put(xs[1], rt);
+    eta = block_sum_x(r[0] * rt[0] + r[1] * rt[1], xs[1], gp);
     const bool rec = a.eta_hist && tid == 0 && sys == 0;
     if (rec) a.eta_hist[0] = (double)eta;
     f32x2 p = rt, ups;
-    if constexpr (PW) put_private(pw_p, p, gp);
-    else {
-        put(xs[0], p);
-        __syncthreads();
-    }
+    put_private(pw_p, p, gp);
     int iters = a.max_iters;
     const float tol = (float)a.exit_tol;
     for (int it = 0; it < a.max_iters; ++it) {                             // gato_pcg.cuh:348
         ups = times_window(sm, wp_);
-        float v, hx = 0.f;
-        if constexpr (PW) {
-            put(xs[0], ups);
-            v = block_sum_x(p[0] * ups[0] + p[1] * ups[1], xs[0], hx);
-        } else v = block_sum(p[0] * ups[0] + p[1] * ups[1]);
+        float hx = 0.f;
+        put(xs[0], ups);
+        const float v = block_sum_x(p[0] * ups[0] + p[1] * ups[1], xs[0], hx);
         const float alpha = quotient(eta, v);
         lam += alpha * p;
         r -= alpha * ups;
-        if constexpr (PW) {
-            gr -= alpha * hx;
-            asm volatile("" : "+v"(gr) : : "memory");      // the halo value first: no wait for hx BETWEEN the two LDS writes
-            put_private(pw_r, r, gr);
-        } else {
-            put(xs[1], r);
-            __syncthreads();
-        }
+        gr -= alpha * hx;
+        asm volatile("" : "+v"(gr) : : "memory");          // the halo value first: no wait for hx BETWEEN the two LDS writes
+        put_private(pw_r, r, gr);
         rt = times_window(pm, wr_);
-        if constexpr (PW) {
-            put(xs[1], rt);
-            eta_new = block_sum_x(r[0] * rt[0] + r[1] * rt[1], xs[1], hx);
-        } else eta_new = block_sum(r[0] * rt[0] + r[1] * rt[1]);
+        put(xs[1], rt);
+        eta_new = block_sum_x(r[0] * rt[0] + r[1] * rt[1], xs[1], hx);
         if (rec) a.eta_hist[it + 1] = (double)eta_new;
         if (__builtin_amdgcn_readfirstlane((int)(fabsf(eta_new) < tol))) { iters = it; break; }                   // :404-411
         const float beta = quotient(eta_new, eta);
         p = rt + beta * p;
         eta = eta_new;
-        if constexpr (PW) {
-            gp = hx + beta * gp;
-            asm volatile("" : "+v"(gp) : : "memory");
-            put_private(pw_p, p, gp);
-        } else {
-            put(xs[0], p);
-            __syncthreads();
-        }
+        gp = hx + beta * gp;
+        asm volatile("" : "+v"(gp) : : "memory");
+        put_private(pw_p, p, gp);
     }
     if (active) { dL[(size_t)j * S + r0] = lam[0]; dL[(size_t)j * S + r1] = lam[1]; }
     if (a.dz_helpers && a.dz != nullptr && a.batch <= 1) {       // lambda is complete: release it and tell the helper blocks
@@ -1588,284 +1558,20 @@ __device__ __forceinline__ void pin_reads_then_fmas()
     __builtin_amdgcn_sched_group_barrier(0x002, NFMA - FA * (STEPS + (TAILR > 0 ? 1 : 0)), 0);
 }
 
-// ---- fp32, one workgroup, HYBRID: four two-row waves + four DPP-row waves (round 4) ---------------------------------------
-// The kernel above runs 14/7/50 on six waves - two of the four SIMDs host two of them - and its iteration time steps with
-// the number of waves on the busiest SIMD (same box: K = 36, four waves, 1.05 us per iteration; K = 37, five waves, 1.22;
-// K = 50, six, 1.26; K = 73, eight, 1.45): a SIMD's LDS return path (16 cycles per 16-byte read) and its vector issue are
-// what a product costs.  Here every SIMD hosts ONE two-row wave (wave-private operand windows as above, K2 = K - 16 knots,
-// 36 at most) and ONE wave whose lanes own a 16-lane DPP row per knot (16 knots): row_times_dpp takes the operand window of
-// the lane's own knot from the neighbouring lanes' registers, and the entries of the two neighbouring knots are kept BY THE
-// LANE ITSELF - it fetches the neighbours' upsilon (r~) entries from the shared exchange window after the block sum's barrier
-// and applies the owner's own FMA (r - alpha upsilon, r~ + beta p), exactly what the two-row waves do for their halo rows - so
-// these waves read no operand window at all and need no barrier beyond the two of the block sums.  Per-row summation order of
-// both lane kinds = the packed form's (even columns + odd columns): the same per-row bits as the kernel above.
-// MEASURED (same box, tools/tune_pcg.run): 14/7/50 1.234 us per iteration against 1.250 for the six two-row waves, 14/7/37 1.197 /
-// 1.215, 14/7/45 1.232 / 1.220 - no gain worth a default: unlike the fp64 kernel, whose products were bound by what a SIMD pulls
-// through its LDS return path, the fp32 iteration is bound by the serial chain around the two block sums (DPP steps, barrier,
-// quotient, halo FMAs), which EVERY wave of the launch repeats - eight waves repeat it on every SIMD twice.  Opt-in (option
-// f32_hybrid), correct and tested (test_f32_hybrid_kernel_every_size_it_serves); the default stays the kernel above.
-#ifndef GATO_F32H_D
-#define GATO_F32H_D 6       // window reads in flight in a two-row product
-#endif
-template <int S>
-__global__ __launch_bounds__(512) void pcg_single_f32h_kernel(PcgLaunch a)
-{
-    constexpr int H = S / 2, SP = pad_to(S, 4), W2 = 4, WT = 8, NT = 64 * WT, L2 = 64 * W2, KD = 4 * (WT - W2), K2MAX = L2 / H;
-    constexpr int MAXK = K2MAX + KD;
-    static_assert(S % 2 == 0 && DppRows<S>::ok && DppRows<S>::lanes == 16, "two rows per lane / one knot per 16-lane DPP row");
-    __shared__ __attribute__((aligned(16))) float xs[2][(MAXK + 2) * SP];       // exchange windows: [0] upsilon (p, r at set-up), [1] r~
-    __shared__ __attribute__((aligned(16))) float wpart[2][4 * WT];
-    constexpr int PK = (128 - 1 + S - 1) / S + 1 + 2;                 // knots a two-row wave's 128 rows can span + a halo knot on either side
-    static_assert(4 * S - 2 <= 64, "private windows: one halo row per lane");
-    __shared__ __attribute__((aligned(16))) float pwin[2][W2 * PK * SP];        // two-row waves: [0] = p, [1] = r, wave after wave
-    __shared__ __attribute__((aligned(16))) float hscr[WT * (4 * S * S + 6 * S)];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool two = __builtin_amdgcn_readfirstlane(wave) < W2;
-    const int K = a.K;
-    if (a.batch <= 1 && blockIdx.x > 0) {
-        one_system_helper<float, S>(a, hscr);
-        return;
-    }
-    const size_t sys = a.batch > 1 ? blockIdx.x : 0;
-    const int K2 = K > KD ? K - KD : 0;
-    int j, r0;                                    // knot, (first) row in it
-    bool active;
-    if (two) { j = tid / H; r0 = 2 * (tid - j * H); active = j < K2; }
-    else { j = K2 + ((tid - L2) >> 4); r0 = tid & 15; active = j < K && r0 < S; }
-    const int rc = r0 < S ? r0 : S - 1;           // idle DPP lanes read inside the windows
-    const int row0 = j * S + r0;
-
-    const float *__restrict__ dS = static_cast<const float *>(a.S_bd) + sys * 3 * S * S * K;
-    const float *__restrict__ dP = static_cast<const float *>(a.P_bd) + sys * 3 * S * S * K;
-    const float *__restrict__ dG = static_cast<const float *>(a.gamma) + sys * S * K;
-    float *__restrict__ dL = static_cast<float *>(a.lambda) + sys * S * K;
-
-    // two-row lanes: pairs (row a, row b) of S (3S) and Pinv (3S); DPP lanes: S row (3S floats), Pinv row (3S floats)
-    float mm[12 * S];
-    {
-        const bool use_img = a.imgS != nullptr;
-        const size_t ld = (size_t)a.img_ld;
-        const int rowc = active ? row0 : 0;
-        const size_t base = (size_t)(active ? j : 0) * 3 * S * S + rc;
-        auto ok_col = [&](int c) { return active && !(j == 0 && c < S) && !(j == K - 1 && c >= 2 * S); };
-        if (two) {
-            f32x2 sv[3 * S], pv[3 * S];
-            if (use_img) {
-                const float *iS = static_cast<const float *>(a.imgS) + rowc, *iP = static_cast<const float *>(a.imgP) + rowc;
-#pragma unroll
-                for (int c = 0; c < 3 * S; ++c) sv[c] = *reinterpret_cast<const f32x2 *>(iS + c * ld);
-#pragma unroll
-                for (int c = 0; c < 3 * S; ++c) pv[c] = *reinterpret_cast<const f32x2 *>(iP + c * ld);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3 * S; ++c) sv[c] = *reinterpret_cast<const f32x2 *>(dS + base + c * S);
-#pragma unroll
-                for (int c = 0; c < 3 * S; ++c) pv[c] = *reinterpret_cast<const f32x2 *>(dP + base + c * S);
-            }
-#pragma unroll
-            for (int c = 0; c < 3 * S; ++c) {
-                const bool ok = use_img ? active : ok_col(c);
-                mm[2 * c] = ok ? sv[c][0] : 0.f; mm[2 * c + 1] = ok ? sv[c][1] : 0.f;
-                mm[6 * S + 2 * c] = ok ? pv[c][0] : 0.f; mm[6 * S + 2 * c + 1] = ok ? pv[c][1] : 0.f;
-            }
-        } else {
-            if (use_img) {
-                const float *iS = static_cast<const float *>(a.imgS) + rowc, *iP = static_cast<const float *>(a.imgP) + rowc;
-#pragma unroll
-                for (int c = 0; c < 3 * S; ++c) mm[c] = iS[c * ld];
-#pragma unroll
-                for (int c = 0; c < 3 * S; ++c) mm[3 * S + c] = iP[c * ld];
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3 * S; ++c) mm[c] = dS[base + (size_t)c * S];
-#pragma unroll
-                for (int c = 0; c < 3 * S; ++c) mm[3 * S + c] = dP[base + (size_t)c * S];
-            }
-#pragma unroll
-            for (int c = 0; c < 3 * S; ++c) {
-                const bool ok = use_img ? active : ok_col(c);
-                mm[c] = ok ? mm[c] : 0.f;
-                mm[3 * S + c] = ok ? mm[3 * S + c] : 0.f;
-            }
-        }
-    }
-    for (int i = tid; i < 2 * (MAXK + 2) * SP; i += NT) (&xs[0][0])[i] = 0.f;
-    for (int i = tid; i < 2 * W2 * PK * SP; i += NT) (&pwin[0][0])[i] = 0.f;
-    if (tid < 2 * 4 * WT) (&wpart[0][0])[tid] = 0.f;
-    __syncthreads();
-    // two-row waves: the wave's rows [R0, R1), its private windows (slot 0 = knot jf - 1) and the lane's halo row
-    int hoff = 0, hpo = 0, own_po = 0, win_po = 0;
-    bool hvalid = false;
-    float *pw_p = &pwin[0][0], *pw_r = &pwin[1][0];
-    if (two) {
-        const int R0 = 128 * wave, R1 = min(R0 + 128, K2 * S);
-        pw_p = &pwin[0][wave * PK * SP]; pw_r = &pwin[1][wave * PK * SP];
-        if (R0 < R1) {
-            const int jf = R0 / S, jl = (R1 - 1) / S, base_row = (jf - 1) * S;
-            const int nb = R0 - base_row, na = (jl + 2) * S - R1;
-            const int hrow = lane < nb ? base_row + lane : R1 + (lane - nb);
-            hvalid = lane < nb + na && hrow >= 0 && hrow < K * S;
-            const int hj = hvalid ? hrow / S : 0, hr = hvalid ? hrow - hj * S : 0;
-            hoff = hvalid ? (hj + 1) * SP + hr : 0;
-            hpo = hvalid ? (hj - jf + 1) * SP + hr : 0;
-            own_po = active ? (j - jf + 1) * SP + r0 : 0;
-            win_po = active ? (j - jf) * SP : 0;
-        }
-    }
-    const int xl_o = j * SP + rc, xr_o = (j + 2) * SP + rc;          // DPP lanes: the lane's row index in knots j - 1 and j + 1 of an exchange window
-
-    // two-row lanes: y = [L M R]_(rows a, b) . window, packed FMAs, even and odd columns in chains of their own (as above)
-    auto times_window = [&](int which, const float *xw) -> f32x2 {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        f32x2 acc = {0.f, 0.f}, acc1 = {0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-#pragma unroll
-            for (int i = 0; i < SP / 4; ++i) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(xw + b * SP + i * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (i * 4 + e < S) {
-                        const int c = (which ? 3 * S : 0) + b * S + i * 4 + e;
-                        const f32x2 mc = {mm[2 * c], mm[2 * c + 1]};
-                        if (e & 1) acc1 = __builtin_elementwise_fma(mc, f32x2{v[e], v[e]}, acc1);
-                        else acc = __builtin_elementwise_fma(mc, f32x2{v[e], v[e]}, acc);
-                    }
-            }
-        }
-        // (the compiler issues all twelve reads up front: 48 landing registers in a kernel whose two-row lanes hold 168 of matrix)
-        pin_reads_then_fmas<GATO_F32H_D, 3 * (SP / 4), 3 * S, 3, 1>();
-        return acc + acc1;
-    };
-    // DPP lanes: the same row product with the window in registers: the neighbours' entries xl, xr and the lane's own x
-    auto times_dpp = [&](int which, float xl, float x, float xr) -> float {
-        const float x3[3] = {xl, x, xr};
-        return row_times_dpp<float, S>(*reinterpret_cast<const float(*)[3 * S]>(mm + (which ? 3 * S : 0)), x3);
-    };
-    unsigned epoch = 0;
-    // block sum; after its barrier the lane fetches from the exchange window `xw` what its halo state needs: hx (two-row lanes:
-    // the entry of their halo row; DPP lanes: the entry of their row index in knot j - 1) and hy (DPP lanes: knot j + 1)
-    auto block_sum_x = [&](float prod, const float *xw, float &hx, float &hy) -> float {
-        ++epoch;
-        float *wp = wpart[epoch & 1];
-        partials_store(wp, wave, lane, prod);
-        __syncthreads();
-        hx = xw[two ? hoff : xl_o];
-        hy = xw[two ? hoff : xr_o];
-        return partials_total_all8<float>(wp, lane);
-    };
-    auto put_x = [&](float *buf, f32x2 v) {                            // own entries into an exchange window
-        if (active) {
-            if (two) *reinterpret_cast<f32x2 *>(buf + (j + 1) * SP + r0) = v;
-            else buf[(j + 1) * SP + r0] = v[0];
-        }
-    };
-    auto put_private = [&](float *pw, f32x2 v, float g) {               // two-row lanes only
-        if (active) *reinterpret_cast<f32x2 *>(pw + own_po) = v;
-        if (hvalid) pw[hpo] = g;
-        wave_lds_fence();
-    };
-    const float *wp_ = pw_p + win_po, *wr_ = pw_r + win_po;
-
-    f32x2 lam = {0.f, 0.f}, r = {0.f, 0.f};
-    if (active) {
-        r[0] = dG[(size_t)j * S + r0];
-        if (two) r[1] = dG[(size_t)j * S + r0 + 1];
-    }
-    // halo state: two-row lanes g0 = their halo row's entry; DPP lanes g0 / g1 = their row's entry in knots j - 1 / j + 1
-    float gr0 = 0.f, gr1 = 0.f, gp0 = 0.f, gp1 = 0.f;
-    if (a.lambda0) {                                                       // true warm start (opt-in): r = gamma - S lambda0
-        const float *__restrict__ dL0 = static_cast<const float *>(a.lambda0) + sys * S * K;
-        if (active) {
-            lam[0] = dL0[(size_t)j * S + r0];
-            if (two) lam[1] = dL0[(size_t)j * S + r0 + 1];
-        }
-        put_x(xs[0], lam);
-        __syncthreads();
-        if (two) r -= times_window(0, &xs[0][j * SP]);
-        else r[0] -= times_dpp(0, xs[0][xl_o], lam[0], xs[0][xr_o]);
-        __syncthreads();
-    }
-    put_x(xs[0], r);
-    __syncthreads();
-    gr0 = two ? (hvalid ? xs[0][hoff] : 0.f) : xs[0][xl_o];
-    gr1 = two ? 0.f : xs[0][xr_o];
-    f32x2 rt = {0.f, 0.f};
-    if (two) {
-        put_private(pw_r, r, gr0);
-        rt = times_window(1, wr_);                                         // gato_pcg.cuh:316-335
-    } else rt[0] = times_dpp(1, gr0, r[0], gr1);
-    put_x(xs[1], rt);
-    float hx = 0.f, hy = 0.f;
-    float eta = block_sum_x(r[0] * rt[0] + r[1] * rt[1], xs[1], hx, hy), eta_new = 0.f;
-    const bool rec = a.eta_hist && tid == 0 && sys == 0;
-    if (rec) a.eta_hist[0] = (double)eta;
-    f32x2 p = rt, ups = {0.f, 0.f};
-    gp0 = hx; gp1 = two ? 0.f : hy;
-    if (two) {
-        if (!hvalid) gp0 = 0.f;
-        put_private(pw_p, p, gp0);
-    }
-    int iters = a.max_iters;
-    const float tol = (float)a.exit_tol;
-    for (int it = 0; it < a.max_iters; ++it) {                             // gato_pcg.cuh:348
-        if (two) ups = times_window(0, wp_);
-        else ups[0] = times_dpp(0, gp0, p[0], gp1);
-        put_x(xs[0], ups);
-        const float v = block_sum_x(p[0] * ups[0] + p[1] * ups[1], xs[0], hx, hy);
-        const float alpha = quotient(eta, v);
-        lam += alpha * p;
-        r -= alpha * ups;
-        gr0 -= alpha * hx;
-        if (two) {
-            asm volatile("" : "+v"(gr0) : : "memory");     // the halo value first: no wait for hx BETWEEN the two LDS writes
-            put_private(pw_r, r, gr0);
-            rt = times_window(1, wr_);
-        } else {
-            gr1 -= alpha * hy;
-            rt[0] = times_dpp(1, gr0, r[0], gr1);
-        }
-        put_x(xs[1], rt);
-        eta_new = block_sum_x(r[0] * rt[0] + r[1] * rt[1], xs[1], hx, hy);
-        if (rec) a.eta_hist[it + 1] = (double)eta_new;
-        if (__builtin_amdgcn_readfirstlane((int)(fabsf(eta_new) < tol))) { iters = it; break; }                   // :404-411
-        const float beta = quotient(eta_new, eta);
-        p = rt + beta * p;
-        eta = eta_new;
-        gp0 = hx + beta * gp0;
-        if (two) {
-            asm volatile("" : "+v"(gp0) : : "memory");
-            put_private(pw_p, p, gp0);
-        } else gp1 = hy + beta * gp1;
-    }
-    if (active) {
-        dL[(size_t)j * S + r0] = lam[0];
-        if (two) dL[(size_t)j * S + r0 + 1] = lam[1];
-    }
-    if (a.dz_helpers && a.dz != nullptr && a.batch <= 1) {       // lambda is complete: release it and tell the helper blocks
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store((gi32 *)a.dz_flag, a.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (tid == 0) {
-        const bool dz_lost = a.dz_helpers && a.dz != nullptr && a.batch <= 1 &&
-                             __hip_atomic_load((gi32 *)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_id;
-        a.iters[sys] = dz_lost ? -1 : iters;
-        if (a.final_eta && sys == 0) *a.final_eta = (double)eta_new;
-    }
-}
-
+// (Round 4 also had a HYBRID fp32 kernel here - four two-row waves + four DPP-row waves, one of each per SIMD, option f32_hybrid.
+// Measured equal to the kernel above for two rounds (14/7/50: 1.234 against 1.250 us per iteration, 14/7/45 1.232 / 1.220): the
+// fp32 iteration is bound by the serial chain around its two block sums, which every wave repeats, not by what a SIMD pulls
+// through its LDS return path.  Removed in round 5.)
 // threads of the two-rows-per-lane kernel: 2*3S*2 matrix registers + window + state must stay under the cap
 // ---- fp64, one workgroup, MIXED rows per lane (IIWA 14/7/50 in fp64 = BASELINE configs[1]) -------------------------------
 // The one-workgroup loop is bound by its LDS reads: every lane reads the 3S-entry operand window of its knot for each
 // of the two products (16-byte broadcast reads), and 700 rows x 84 doubles do not fit the register file, so part of Pinv
 // lives in LDS as well (pcg_resident_kernel<double, 14, 704, NL = 24>: 54 reads per lane and iteration on 11 waves = 594
 // wave-reads).  Here 8 waves instead of 11: the lanes of the first W2 waves own TWO adjacent rows of a knot each - both
-// rows share every window read, their S rows sit in registers (2 x 3S doubles) and their Pinv rows in LDS as (row a, row b)
-// pairs, one 16-byte read per column - and the other waves own one row each with S and Pinv entirely in registers:
-// 8 x 42 window reads + W2 x 42 Pinv reads = 462 wave-reads per iteration.  Same recurrence, same per-row summation order
-// as every other kernel of the family (a row's 3S products are added left to right); block sums as in partials_store.
+// rows share every window read - and the other waves own one knot per 16-lane DPP row with S and Pinv entirely in registers
+// (round 2's layout had dense one-row waves there: option mixed_dense, removed in round 5 after two rounds of A/B at 1.94
+// against 1.54 us per iteration).  Same recurrence, same per-row summation order as every other kernel of the family (a row's
+// 3S products are added left to right); block sums as in partials_store.
 // ABL: timing-only switches (bench.py's latency floor) as COMPILE-TIME constants - 3 no products, 4 no block sums, 15 loop
 // skeleton; with run-time switches this loop compiles 40 % slower than the production kernel, which is no yardstick.
 #ifndef GATO_L2_HELPERS
@@ -1901,30 +1607,29 @@ __global__ __launch_bounds__(512) void pcg_single_f32h_kernel(PcgLaunch a)
 #ifndef GATO_F64M_D0
 #define GATO_F64M_D0 8      // reads in flight: two-row lanes, S product (21 reads, 84 FMAs)
 #endif
-#ifndef GATO_F64M_D1
-#define GATO_F64M_D1 6      // one-row lanes of the dense layout, either product (21 reads, 42 FMAs); 0 = the compiler's order
-#endif
 #ifndef GATO_F64M_D2
 #define GATO_F64M_D2 8      // two-row lanes, Pinv product (60 or 63 reads, 84 FMAs)
 #endif
-template <int S, int W2, int WT, int ABL = 0, bool DR = false, int K2MAX = 0, int NPR = 0>
+template <int S, int W2, int WT, int ABL = 0, int K2MAX = 0, int NPR = 0>
 __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 {
     typedef double T;
     typedef double V2 __attribute__((ext_vector_type(2)));
     constexpr int SP = pad_to(S, 2), NT = 64 * WT, L2 = 64 * W2;
-    constexpr int KD = DR ? 4 * (WT - W2) : 0;                    // knots of the DPP waves (one per 16-lane row)
-    constexpr int L2U = DR ? K2MAX * (S / 2) : L2;                // two-row lanes that can own rows
-    constexpr int LSTR = DR ? L2U + 1 : L2;                       // lane slots per Pinv column in LDS (DR: + one slot of zeros for the idle lanes)
+    constexpr int KD = 4 * (WT - W2);                             // knots of the DPP waves (one per 16-lane row)
+    constexpr int L2U = K2MAX * (S / 2);                          // two-row lanes that can own rows
+    constexpr int LSTR = L2U + 1;                                 // lane slots per Pinv column in LDS (+ one slot of zeros for the idle lanes)
     constexpr int NC = 3 * S - NPR;                               // column pairs of a two-row lane in LDS (the other 3S + NPR in registers)
-    constexpr int MAXK = DR ? K2MAX + KD : (2 * L2 + (NT - L2) + S - 1) / S;
+    constexpr int MAXK = K2MAX + KD;
     static_assert(S % 2 == 0 && W2 >= 1 && W2 < WT && WT <= 16, "two adjacent rows of one knot per lane in the first W2 waves");
-    static_assert(!DR || (DppRows<S>::ok && DppRows<S>::lanes == 16 && L2U <= L2 && L2U < NT && NPR >= 0 && NPR < 3 * S), "DPP rows: one knot per 16 lanes");
+    static_assert(DppRows<S>::ok && DppRows<S>::lanes == 16 && L2U <= L2 && L2U < NT && NPR >= 0 && NPR < 3 * S, "DPP rows: one knot per 16 lanes");
     // ONE operand window: p while the S product reads it, r while the Pinv product does.  Either is written after a barrier
     // behind the other's last read (the block sum's), so the two never meet - and a second window's 5.8 KB are what lets the
     // Pinv pairs of 238 two-row lanes fit the LDS with only NPR of them in registers
     __shared__ __attribute__((aligned(16))) T xs[(MAXK + 2) * SP];
-    __shared__ __attribute__((aligned(32))) T wpart[2][4 * WT];
+    constexpr int WPW = WT < 8 ? 8 : WT;                                           // partials_total_all8 reads eight waves' slots (zeros beyond WT)
+    __shared__ __attribute__((aligned(32))) T wpart[2][4 * WPW];
+    static_assert(WT > 8 || sizeof(wpart) / 2 >= 32 * sizeof(T), "partials_total_all8 reads 32 values per buffer");
     __shared__ __attribute__((aligned(16))) V2 ptail[NC][LSTR];                    // Pinv entry NPR + c of (row a, row b) of a two-row lane
     static_assert(sizeof(xs) + sizeof(wpart) + sizeof(ptail) <= 160 * 1024, "LDS of one CU");
 
@@ -1943,27 +1648,21 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         return;
     }
     const size_t sys = a.batch > 1 ? blockIdx.x : 0;
-    // lane -> row(s).  Dense layout: two-row lanes rows 2 tid, 2 tid + 1, then one row per lane.  DR: the first K - KD knots (at most
-    // K2MAX) in the two-row lanes, the last KD knots one per 16-lane row of the other waves.
+    // lane -> row(s): the first K - KD knots (at most K2MAX) in the two-row lanes (rows 2 tid, 2 tid + 1), the last KD knots one
+    // per 16-lane row of the other waves.
     int row0, j, r0, tp = tid;                                                      // first row, its knot, its row in the knot; lane slot in ptail
     bool active;
-    if constexpr (DR) {
-        const int K2 = K > KD ? K - KD : 0;
-        if (two) {
-            row0 = 2 * tid; j = row0 / S; r0 = row0 - j * S;
-            active = j < K2;
-            tp = tid < L2U ? tid : L2U;
-        } else {
-            const int q = (tid - L2) >> 4;
-            r0 = tid & 15; j = K2 + q;
-            active = j < K && r0 < S;
-            row0 = j * S + r0;
-            tp = 0;
-        }
+    const int K2 = K > KD ? K - KD : 0;
+    if (two) {
+        row0 = 2 * tid; j = row0 / S; r0 = row0 - j * S;
+        active = j < K2;
+        tp = tid < L2U ? tid : L2U;
     } else {
-        row0 = two ? 2 * tid : 2 * L2 + (tid - L2);
-        j = row0 / S; r0 = row0 - j * S;
-        active = row0 < K * S;
+        const int q = (tid - L2) >> 4;
+        r0 = tid & 15; j = K2 + q;
+        active = j < K && r0 < S;
+        row0 = j * S + r0;
+        tp = 0;
     }
     constexpr int abl = ABL;
 
@@ -1976,23 +1675,18 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
     // The loads are issued in BATCHES with nothing that needs their data in between: written column by column (load S, load
     // Pinv, select, store the Pinv pair to LDS) the compiler reused one set of registers and waited for every column's loads
     // before the next (84 memory round trips in a row: 9 us of a 198 us launch even with every line in L2).
-    // Two-row lanes keep 3S + NPR column PAIRS (row a, row b) in registers, the other 3S - NPR in LDS.  Dense layout: all of S
-    // in registers, all of Pinv in LDS.  DR: the EVEN columns of both matrices in registers (and the last NPR odd ones of Pinv),
-    // the odd ones in LDS - either product then reads 3S/2 windows + 3S/2 pairs, one read per two FMAs throughout: the S
-    // product is bound by the vector units beside a DPP wave (LDS reads are free there), the Pinv product was bound by its
-    // 63 reads (stamps: 850 and 1230 cycles).
+    // Two-row lanes keep 3S + NPR column PAIRS (row a, row b) in registers, the other 3S - NPR in LDS: the EVEN columns of both
+    // matrices in registers (and the last NPR odd ones of Pinv), the odd ones in LDS - either product then reads 3S/2 windows +
+    // 3S/2 pairs, one read per two FMAs throughout.
     T m[6 * S + 2 * NPR];
     auto in_reg = [](int which, int c) -> bool {
-        if (!DR) return which == 0;
         return c % 2 == 0 || (which == 1 && c >= 3 * S - 2 * NPR);
     };
     auto reg_idx = [](int which, int c) -> int {             // pair index in m (entries 2 i, 2 i + 1)
-        if (!DR) return c;
         if (c % 2 == 0) return (which ? 3 * S / 2 : 0) + c / 2;
         return 3 * S + (c - (3 * S - 2 * NPR)) / 2;
     };
     auto lds_idx = [](int which, int c) -> int {             // column slot in ptail
-        if (!DR) return c;
         return (which ? 3 * S / 2 : 0) + (c - 1) / 2;
     };
     {
@@ -2005,9 +1699,9 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         };
         if (a.imgS != nullptr) {
             // the assembly launch of this solve also left S and Pinv transposed (column c of ALL rows contiguous, zeros where a
-            // block or a row does not exist): the lane's entries are unit-stride across the wave, no boundary selects (DR: a lane
+            // block or a row does not exist): the lane's entries are unit-stride across the wave, no boundary selects (a lane
             // without rows of its own reads rows of other lanes and drops them)
-            const int rowc = DR ? (active ? row0 : 0) : row0;
+            const int rowc = active ? row0 : 0;
             const T *__restrict__ iS = static_cast<const T *>(a.imgS) + rowc, *__restrict__ iP = static_cast<const T *>(a.imgP) + rowc;
             const size_t ld = (size_t)a.img_ld;
             if (two) {
@@ -2015,7 +1709,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 #pragma unroll
                 for (int c = 0; c < 3 * S; ++c) sv[c] = *reinterpret_cast<const V2 *>(iS + c * ld);      // row0 even, ld even: 16-byte aligned
 #pragma unroll
-                for (int c = 0; c < 3 * S; ++c) keep_pair(0, c, (!DR || active) ? sv[c] : V2{0, 0});
+                for (int c = 0; c < 3 * S; ++c) keep_pair(0, c, active ? sv[c] : V2{0, 0});
                 constexpr int PB = 14;
 #pragma unroll
                 for (int c0 = 0; c0 < 3 * S; c0 += PB) {
@@ -2023,17 +1717,15 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 #pragma unroll
                     for (int q = 0; q < PB; ++q) pv[q] = *reinterpret_cast<const V2 *>(iP + (c0 + q) * ld);
 #pragma unroll
-                    for (int q = 0; q < PB; ++q) keep_pair(1, c0 + q, (!DR || active) ? pv[q] : V2{0, 0});
+                    for (int q = 0; q < PB; ++q) keep_pair(1, c0 + q, active ? pv[q] : V2{0, 0});
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 3 * S; ++c) m[c] = iS[c * ld];
 #pragma unroll
                 for (int c = 0; c < 3 * S; ++c) m[3 * S + c] = iP[c * ld];
-                if constexpr (DR) {
 #pragma unroll
-                    for (int c = 0; c < 6 * S; ++c) m[c] = active ? m[c] : (T)0;
-                }
+                for (int c = 0; c < 6 * S; ++c) m[c] = active ? m[c] : (T)0;
             }
         } else if (two) {
             V2 sv[3 * S];
@@ -2065,7 +1757,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         }
     }
     for (int i = tid; i < (MAXK + 2) * SP; i += NT) xs[i] = (T)0;
-    if (tid < 2 * 4 * WT) (&wpart[0][0])[tid] = (T)0;
+    for (int i = tid; i < 2 * 4 * WPW; i += NT) (&wpart[0][0])[i] = (T)0;
     __syncthreads();
 
     // the lane's Pinv pairs in LDS: column NPR + c at ptail[c][tp].  A few LDS base registers, the rest 16-bit immediate offsets.
@@ -2105,35 +1797,16 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
                     }
                 }
             }
-            if constexpr (DR) {
-                if (which == 0) pin_reads_then_fmas<GATO_F64M_D0, NW + 3 * S / 2, 6 * S, 4, 2>();
-                else pin_reads_then_fmas<GATO_F64M_D2, NW + 3 * S / 2 - NPR, 6 * S, 4, 2>();
-            } else {
-                if (which == 0) pin_reads_then_fmas<GATO_F64M_D0, NW, 6 * S, 4, 1>();
-                else pin_reads_then_fmas<GATO_F64M_D2, NW + NC, 6 * S, 4, 3>();
-            }
-        } else if constexpr (DR) {
+            if (which == 0) pin_reads_then_fmas<GATO_F64M_D0, NW + 3 * S / 2, 6 * S, 4, 2>();
+            else pin_reads_then_fmas<GATO_F64M_D2, NW + 3 * S / 2 - NPR, 6 * S, 4, 2>();
+        } else {
             asm volatile("; one row per lane, DPP rows" ::: "memory");
             const int rc = r0 < S ? r0 : S - 1;                                  // idle lanes read inside the window (their rows are zero)
             const T x3[3] = {xw[rc], own[0], xw[2 * SP + rc]};                   // the lane's row index in knots j - 1, j, j + 1
             ya = row_times_dpp<T, S>(*reinterpret_cast<const T(*)[3 * S]>(m + (which ? 3 * S : 0)), x3);
-        } else {
-            asm volatile("; one row per lane" ::: "memory");
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-#pragma unroll
-                for (int i = 0; i < SP / 2; ++i) {
-                    const V2 v = *reinterpret_cast<const V2 *>(xw + b * SP + i * 2);
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        if (i * 2 + e < S) ya = gato::fmaT(m[(which ? 3 * S : 0) + b * S + i * 2 + e], v[e], ya);
-                }
-            }
-            if constexpr (GATO_F64M_D1 > 0) pin_reads_then_fmas<GATO_F64M_D1, NW, 3 * S, 2, 1>();
         }
         return V2{ya, yb};
     };
-    unsigned epoch = 0;
 #ifdef GATO_F64M_STAMP      // scratch builds only (tools/f64m_stamps.py): s_memtime at the phase boundaries of ONE iteration, per wave
     unsigned long long st_[16] = {};
     bool st_on = false;
@@ -2144,7 +1817,6 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
     // `which`: the partials buffer of this call site - consecutive block sums alternate between the two (p . upsilon in [0],
     // r . r~ in [1]), so a wave may store its next partials while a slower one still reads the previous ones
     auto block_sum = [&](T prod, int si, int which) -> T {
-        ++epoch;
         if (abl & 4) return (T)1 + prod * (T)1e-30;
         T *wp = wpart[which];
         partials_store(wp, wave, lane, prod);
@@ -2309,20 +1981,17 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
     }
 }
 
-// shape of the mixed kernel per STATE_SIZE (0 = none): waves with two rows per lane, waves in all
-// dr: the one-row waves own 16-lane DPP rows; then k2 = knots the two-row lanes can take (LDS), npr = their Pinv columns in registers
-template <int S> struct MixedCfg { static constexpr int w2 = 0, wt = 0, k2 = 0, npr = 0; static constexpr bool dr = false; };
-template <> struct MixedCfg<14> { static constexpr int w2 = 4, wt = 8, k2 = 34, npr = 1; static constexpr bool dr = true; };   // 34 + 4 x 4 = 50 knots
-template <int S> struct MixedCfgDense { static constexpr int w2 = 0, wt = 0; };                                                  // round 2's layout (option mixed_dense)
-template <> struct MixedCfgDense<14> { static constexpr int w2 = 3, wt = 8; };      // 3 x 128 + 5 x 64 = 704 rows = 50 knots
+// shape of the mixed kernel per STATE_SIZE (0 = none): waves with two rows per lane, waves in all (the others own 16-lane DPP rows,
+// one knot each), k2 = knots the two-row lanes can take (LDS), npr = their Pinv columns in registers
+template <int S> struct MixedCfg { static constexpr int w2 = 0, wt = 0, k2 = 0, npr = 0; };
+template <> struct MixedCfg<14> { [[maybe_unused]] static constexpr int w2 = 4, wt = 8, k2 = 34, npr = 1; };   // 34 + 4 x 4 = 50 knots
 template <int S> constexpr int mixed_rows()
 {
     if (MixedCfg<S>::wt <= 0) return 0;
-    if (MixedCfg<S>::dr) return (MixedCfg<S>::k2 + 4 * (MixedCfg<S>::wt - MixedCfg<S>::w2)) * S;
-    return 128 * MixedCfg<S>::w2 + 64 * (MixedCfg<S>::wt - MixedCfg<S>::w2);
+    return (MixedCfg<S>::k2 + 4 * (MixedCfg<S>::wt - MixedCfg<S>::w2)) * S;
 }
 
-template <int S> struct PairThreads { static constexpr int v = (12 * S + 3 * S + 48) <= 256 ? 512 : ((12 * S + 3 * S + 48) <= 512 ? 256 : 0); };
+template <int S> struct PairThreads { static constexpr int v = 4 * S - 2 > 64 ? 0 : (12 * S + 3 * S + 48) <= 256 ? 512 : ((12 * S + 3 * S + 48) <= 512 ? 256 : 0); };   // (private windows: one halo row per lane)
 template <> struct PairThreads<14> { static constexpr int v = 512; };     // measured: 248 VGPRs, no spill at the 256 cap
 
 // Generic rule for shapes added at build time: VGPRs per lane ~ matrix rows (6S words, x2 for fp64) + the
@@ -2559,18 +2228,7 @@ int launch_pcg_single(const PcgLaunch &a, bool mr, hipStream_t st)
             // one system: + helper blocks (enough waves for one knot each: they also do dz), see pcg_single_f64m_kernel
             const int helpers = (a.K + a.threads / 64 - 1) / (a.threads / 64);
             const dim3 grid(a.batch > 1 ? a.batch : 1 + 8 * helpers);
-            // more than four two-row waves, at most 36 + 16 knots (S = 14): the hybrid of two-row and DPP-row waves, always 8 waves
-            bool hybrid = false;
-            if constexpr (DppRows<S>::ok && DppRows<S>::lanes == 16 && PT >= 512) {
-                hybrid = !a.shared_windows && a.f32_hybrid && a.threads > 256 && a.K <= 256 / (S / 2) + 16;
-                if (hybrid) {
-                    const dim3 gridh(a.batch > 1 ? a.batch : 1 + 8 * ((a.K + 7) / 8));
-                    hipLaunchKernelGGL((pcg_single_f32h_kernel<S>), gridh, dim3(512), 0, st, a);
-                }
-            }
-            if (hybrid) { }
-            else if (a.shared_windows) hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT, false>), grid, dim3(a.threads), 0, st, a);
-            else hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT, true>), grid, dim3(a.threads), 0, st, a);
+            hipLaunchKernelGGL((pcg_single_f32x2_kernel<S, PT>), grid, dim3(a.threads), 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;
@@ -2579,8 +2237,6 @@ int launch_pcg_single(const PcgLaunch &a, bool mr, hipStream_t st)
     if constexpr (sizeof(T) == 8 && MixedCfg<S>::wt > 0) {
         if (a.pair == 2) {
             constexpr int W2 = MixedCfg<S>::w2, WT = MixedCfg<S>::wt, K2 = MixedCfg<S>::k2, NPR = MixedCfg<S>::npr;
-            constexpr bool DR = MixedCfg<S>::dr;
-            static_assert(MixedCfgDense<S>::wt == WT, "both layouts: the same launch");
             if (mr || a.groups != 1 || a.threads != 64 * WT || a.K * S > mixed_rows<S>() || a.stamps) {
                 set_error("pcg_resident(mixed): bad launch K=%d threads=%d", a.K, a.threads);
                 return GATO_EINVAL;
@@ -2589,11 +2245,10 @@ int launch_pcg_single(const PcgLaunch &a, bool mr, hipStream_t st)
             static_assert(GATO_L2_HELPERS * WT * S >= mixed_rows<S>(), "one helper wave per knot (they do dz)");
             const dim3 grid(a.batch > 1 ? a.batch : 1 + 8 * GATO_L2_HELPERS), block(64 * WT);          // one system: + helper blocks that warm the L2
             const int abl = a.diag == 2 ? a.ablate : 0;
-            if (a.mixed_dense) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, MixedCfgDense<S>::w2, WT, 0>), grid, block, 0, st, a);
-            else if (abl == 3) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 3, DR, K2, NPR>), grid, block, 0, st, a);
-            else if (abl == 4) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 4, DR, K2, NPR>), grid, block, 0, st, a);
-            else if (abl == 15) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 15, DR, K2, NPR>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, GATO_F64M_DEV_ABL, DR, K2, NPR>), grid, block, 0, st, a);
+            if (abl == 3) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 3, K2, NPR>), grid, block, 0, st, a);
+            else if (abl == 4) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 4, K2, NPR>), grid, block, 0, st, a);
+            else if (abl == 15) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 15, K2, NPR>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, GATO_F64M_DEV_ABL, K2, NPR>), grid, block, 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));
             return GATO_OK;

@@ -62,24 +62,42 @@ except ImportError:                     # not built: array.array / numpy below (
 def _from_list(a, code, dt):
     """Python list / tuple -> contiguous array.  The reference's callers pass lists (test_pendulum_5.py:9-25) and the copy of
     their tens of thousands of Python floats is most of a call's host time: _gato_fastseq.pack (exact-type fast paths in C,
-    include/gato_pyseq.h) where it is built, else array.array (1.6 x faster than numpy), with the same double -> float
-    narrowing.  Anything those refuse (nested lists, non-numbers) goes the numpy way and fails there."""
+    include/gato_pyseq.h) where it is built - its errors ARE the binding's errors (an index that does not fit 32 bits raises
+    OverflowError, a float in an index list TypeError: exactly what the pybind11 module raises for the same input) - else
+    array.array (1.6 x faster than numpy), with the same double -> float narrowing and the same refusals for index lists."""
     if _fs is not None:
-        try:
-            return np.frombuffer(_fs.pack(a, code), dt)
-        except (TypeError, OverflowError, ValueError):
-            pass
+        return np.frombuffer(_fs.pack(a, code), dt)
     try:
         return np.frombuffer(array.array(code, a), dt)
     except (TypeError, OverflowError):
-        return np.ascontiguousarray(np.asarray(a, np.float64), dt) if code != "i" else np.ascontiguousarray(a, np.int32)
+        if code == "i":                 # never numpy's silent truncation / wrap of an index
+            raise
+        return np.ascontiguousarray(np.asarray(a, np.float64), dt)
+
+
+def _index_array(a):
+    """CSR index array (list, tuple, numpy array of any integer type) -> contiguous int32, REFUSING what does not fit: an int64 /
+    unsigned entry beyond 32 bits raises OverflowError, a float array TypeError - as the pybind11 module does (gato_pyseq.h);
+    never numpy's silent wrap."""
+    if isinstance(a, np.ndarray) and a.dtype == np.int32 and a.flags.c_contiguous:
+        return a
+    if isinstance(a, (list, tuple)):
+        return _from_list(a, "i", np.int32)
+    if _fs is not None:
+        return np.frombuffer(_fs.pack(a, "i"), np.int32)
+    arr = np.asarray(a)
+    if arr.dtype.kind not in "iu":
+        raise TypeError(f"index array of dtype {arr.dtype}: integers expected")
+    if arr.size and (int(arr.max()) > 2 ** 31 - 1 or int(arr.min()) < -2 ** 31):
+        raise OverflowError("index does not fit 32 bits")
+    return np.ascontiguousarray(arr, np.int32)
 
 
 def linsys_solve(G_row, G_col, G_val, C_row, C_col, C_val, g_val, c_val, input_lambda,
                  testiters, exit_tol, max_iters, warm_start, rho):
     f64 = _state["precision"] == "f64"
     dt = np.float64 if f64 else np.float32
-    i32 = lambda a: _from_list(a, "i", np.int32) if isinstance(a, (list, tuple)) else np.ascontiguousarray(a, np.int32)
+    i32 = _index_array
     # narrowing as std::vector<float> does
     fl = lambda a: (_from_list(a, "d" if f64 else "f", dt) if isinstance(a, (list, tuple))
                     else np.ascontiguousarray(np.asarray(a, np.float64), dt))

@@ -299,53 +299,6 @@ def pcg_single_reduction(S_bd, Pinv_bd, gamma, S, K, exit_tol, max_iters):
     return lam.reshape(-1), iters
 
 
-def pcg_pipelined(S_bd, Pinv_bd, gamma, S, K, exit_tol, max_iters):
-    """Pipelined PCG (Ghysels-Vanroose) - NOT the reference's recurrence; restated here only to check the opt-in HIP variant
-    (pcg_pipe_kernel, gato_pcg_cg1.hip): the two dots of an iteration are taken BEFORE its two block-tridiagonal products
-    (m = Pinv w, n = S m), and u = Pinv r, w = S u, s = S p, q = Pinv s, z = S q are carried by recurrences.  Same exit test
-    quantity (r . Pinv r, carried as r . u) and iteration numbering as pcg()."""
-    dtype = S_bd.dtype
-    Sl, Sm, Sr = unpack_bd(S_bd, S, K)
-    Pl, Pm, Pr = unpack_bd(Pinv_bd, S, K)
-    lam = np.zeros((K, S), dtype)
-    r = np.asarray(gamma, dtype).reshape(K, S).copy()
-    u = bt_matvec(Pl, Pm, Pr, r)
-    w = bt_matvec(Sl, Sm, Sr, u)
-    p = np.zeros_like(r); s = np.zeros_like(r); q = np.zeros_like(r); z = np.zeros_like(r)
-    alpha = beta = gam_old = dtype.type(0)
-    iters = max_iters
-    tol = dtype.type(exit_tol)
-    for it in range(max_iters + 1):
-        gam = dtype.type(np.sum(r * u, dtype=dtype))
-        delta = dtype.type(np.sum(w * u, dtype=dtype))
-        m = bt_matvec(Pl, Pm, Pr, w)
-        n = bt_matvec(Sl, Sm, Sr, m)
-        if it > 0 and abs(gam) < tol:
-            iters = it - 1
-            break
-        if it == max_iters:
-            break
-        with np.errstate(all="ignore"):
-            if it == 0:
-                beta, alpha = dtype.type(0), gam / delta
-            else:
-                beta = gam / gam_old
-                alpha = gam / (delta - beta * gam / alpha)
-        gam_old = gam
-        z = n + beta * z
-        q = m + beta * q
-        s = w + beta * s
-        p = u + beta * p
-        lam = lam + alpha * p
-        r = r - alpha * s
-        u = u - alpha * q
-        w = w - alpha * z
-    return lam.reshape(-1), iters
-
-
-# --------------------------------------------------------------------------------------------
-# A9: dz back-substitution                        (src/gato_schur.cuh:758-867, D2 fixed)
-# --------------------------------------------------------------------------------------------
 def compute_dz(Ginv_dense, C_dense, g, lam, S, C, K):
     dtype = Ginv_dense.dtype
     n = S + C

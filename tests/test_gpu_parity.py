@@ -431,6 +431,63 @@ print('Test passed')
     assert "first run PCG terminated in " in r.stdout and "avg time:" in r.stdout
 
 
+def test_pybind11_module_at_iiwa_size(tmp_path):
+    """the SHIPPED pybind11 module (bindings/pybind11, what a maintainer would install in place of gpu_library.cu)
+    at the reference's own shape, in a fresh interpreter that sees the .so only: IIWA 14/7/50 (test_IIWA50.py:15-18) as Python
+    lists, as numpy float64 / float32 arrays, with c_val as Python ints (test_pendulum_5.py:18 passes ints) and the CSR index
+    arrays as int64, testiters = 3 - lambda, dz and the iteration count of every form against the C oracle; an index that does
+    not fit 32 bits must raise instead of wrapping."""
+    import subprocess
+    import sys
+    S, C, K = 14, 7, 50
+    s = synth.make_system(S, C, K, seed=0)
+    s.c = np.round(10.0 * s.c)                                 # integer-valued c: passed as Python ints below
+    np.savez(tmp_path / "in.npz", **{k: getattr(s, k) for k in ("G_row", "G_col", "G_val", "C_row", "C_col", "C_val", "g", "c")}, rho=s.rho)
+    code = f"""
+import numpy as np, gpu_library
+assert gpu_library.__file__.endswith('.so')
+d = np.load({str(tmp_path / 'in.npz')!r})
+names = ['G_row', 'G_col', 'G_val', 'C_row', 'C_col', 'C_val', 'g', 'c']
+base = [d[n] for n in names]
+lam0 = np.zeros(14 * 50)
+forms = {{
+    'lists': [a.tolist() for a in base] + [lam0.tolist()],
+    'f64': [np.asarray(a, np.float64) if a.dtype.kind == 'f' else a for a in base] + [lam0],
+    'f32': [np.asarray(a, np.float32) if a.dtype.kind == 'f' else np.asarray(a, np.int32) for a in base] + [lam0.astype(np.float32)],
+    'ints_and_int64': [np.asarray(a, np.int64) if a.dtype.kind in 'iu' else a.tolist() for a in base[:7]] + [[int(v) for v in base[7]], [0] * 700],
+}}
+out = {{}}
+for name, args in forms.items():
+    l, dz = gpu_library.linsys_solve(*args, 3, 1e-6, 100, False, float(d['rho']))
+    assert type(l) is list and type(dz) is list and type(l[0]) is float and len(l) == 700 and len(dz) == 21 * 50 - 7
+    st = gpu_library.last_stats()
+    assert len(st['ms']) == 3 and (st['S'], st['C'], st['K']) == (14, 7, 50)
+    out[name + '_lam'], out[name + '_dz'], out[name + '_iters'] = np.asarray(l), np.asarray(dz), st['iters']
+bad = [np.asarray(a, np.int64) if a.dtype.kind in 'iu' else a for a in base] + [lam0]
+bad[1] = bad[1].copy(); bad[1][5] = 2 ** 40
+try:
+    gpu_library.linsys_solve(*bad, 1, 1e-6, 100, False, float(d['rho']))
+    raise SystemExit('an over-range int64 index was accepted')
+except OverflowError:
+    pass
+np.savez({str(tmp_path / 'out.npz')!r}, **out)
+print('Test passed')
+"""
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "bindings", "pybind11", "build"), GATO_VERBOSE="1")
+    for k in ("GATO_STATE_SIZE", "GATO_CONTROL_SIZE", "GATO_KNOT_POINTS"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Test passed" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+    assert r.stdout.count("first run PCG terminated in ") == 4 and r.stdout.count("avg time:") == 4
+    out = np.load(tmp_path / "out.npz")
+    first = None
+    for name in ("lists", "f64", "f32", "ints_and_int64"):
+        lam, dz, it = out[name + "_lam"], out[name + "_dz"], int(out[name + "_iters"])
+        check_solve(f"pybind11 module 14/7/50 as {name}", s, S, C, K, np.float32, 1e-6, 100, lam, dz, it)
+        first = (lam, dz, it) if first is None else first
+        assert np.array_equal(lam, first[0]) and np.array_equal(dz, first[1]) and it == first[2], name     # the same floats reach the device
+
+
 @pytest.mark.parametrize("S,C,K,dt,opts", [(14, 7, 50, np.float64, {}), (14, 7, 50, np.float32, {}),
                                            (14, 7, 300, np.float64, {}), (2, 1, 40, np.float64, dict(pcg_threads=64)),
                                            (14, 7, 900, np.float32, {}),
@@ -739,6 +796,22 @@ def test_single_reduction_variant(S, C, K, dt, opts):
     sol.close()
 
 
+def test_extra_shape_library():
+    """a shape added at build time (EXTRA_SHAPES) gets the GENERIC launch bounds - S = 16: the fp32 two-rows-per-lane
+    kernel at 256 threads, i.e. FOUR waves under block sums that read eight waves' partials.  build() compiles a one-shape
+    (16, 8) library beside the product (build/ab/libgato_hip_s16.so); whole solves through it (one workgroup, several, batches,
+    both types) against the C oracle, in a process of its own (the library is chosen before the package loads)."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "build", "ab", "libgato_hip_s16.so")
+    assert os.path.exists(lib), "build() makes it: python -c 'import __graft_entry__ as g; g.build()'"
+    env = dict(os.environ, GATO_HIP_LIB=lib, GATO_NO_TUNE="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "extra_shape_worker.py"), "16", "8"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "extra shape ok 16 8" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "('float32', 1, 1, 256)" in r.stdout, r.stdout[-1500:]      # the four-wave two-rows-per-lane launch did run
+
+
 @pytest.mark.parametrize("S,C,K", [(4, 2, 30), (6, 3, 100), (12, 6, 64), (12, 6, 700)])
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_other_compiled_shapes(S, C, K, dt):
@@ -788,10 +861,7 @@ def test_fused_assembly_is_bit_identical_to_the_stage_kernels(S, C, K, seed, dq,
     s = system(S, C, K, seed, dq) if K > 1 else synth.blocks_to_csr(*synth.make_blocks(S, C, 1, seed, dq))
     names = ["G_dense", "C_dense", "Ginv", "S", "Pinv", "gamma", "lam", "dz"]
     ref = None
-    # asm_mode 3: the chunked launch (a workgroup per chunk of consecutive knots, one wave per knot, everything between the
-    # stages in LDS) - one chunk for the whole system, chunks of 8 (halo knots re-derived at every chunk start), of 3 and of 1
-    for opts in (dict(asm_mode=1), dict(asm_mode=2), dict(asm_mode=3), dict(asm_mode=3, asm_chunk=8), dict(asm_mode=3, asm_chunk=3),
-                 dict(asm_mode=3, asm_chunk=1)):
+    for opts in (dict(asm_mode=1), dict(asm_mode=2)):
         sol = make_solver(S, C, K, dt)
         for k, v in opts.items():
             sol.set_option(k, v)
@@ -800,7 +870,7 @@ def test_fused_assembly_is_bit_identical_to_the_stage_kernels(S, C, K, seed, dq,
             sol.linsys(*dev, 1e-8, 50, s.rho)
             sol.check_status()
         got = {n: sol.read_buffer(n) for n in names}
-        assert sol.get_option("last_asm_fused") == {1: 0, 2: 1, 3: 2}[opts["asm_mode"]]
+        assert sol.get_option("last_asm_fused") == {1: 0, 2: 1}[opts["asm_mode"]]
         sol.close()
         if ref is None:
             ref = got
@@ -816,11 +886,9 @@ def test_fused_assembly_batched_and_blocks(dt):
     names = ["G_dense", "Ginv", "S", "Pinv", "gamma", "lam", "dz"]
     from gato_python_amd.solver import Solver
     ref = None
-    for mode in (1, 2, 3, 13):
+    for mode in (1, 2):
         sol = Solver(S, C, K, dt, batch=B)
-        sol.set_option("asm_mode", mode % 10)
-        if mode == 13:
-            sol.set_option("asm_chunk", 7)                     # chunks of 7 of 20 knots: halo knots in every system
+        sol.set_option("asm_mode", mode)
         dev = sol.upload_batch(systems)
         lam, dz = sol.new(B * S * K), sol.new(B * sol.N)
         sol.linsys_batched(*dev, 1e-8, 60, systems[0].rho, lam, dz)
@@ -1332,43 +1400,58 @@ def test_transposed_images_give_the_bits_of_the_block_rows(K, dt):
 
 
 @pytest.mark.parametrize("K,B,warm", [(50, 1, 0), (73, 1, 0), (49, 1, 1), (19, 1, 0), (10, 1, 1), (9, 1, 0), (2, 1, 0), (1, 1, 0), (50, 5, 0), (23, 7, 0)])
-def test_private_windows_give_the_bits_of_the_shared_windows(K, B, warm):
+def test_private_windows_kernel_over_wave_boundaries_batches_and_warm_start(K, B, warm):
     """The fp32 two-rows-per-lane kernel (the reference's precision at its own shape: what the drop-in runs at 14/7/50) keeps
-    WAVE-PRIVATE operand windows: every wave advances the halo rows of r and p itself with the owner's FMA, so the two window
-    barriers of an iteration are gone (default).  shared_windows = 1 is the four-barrier form: the same lambda, dz and
-    iteration count bit for bit - wave boundaries inside a knot (K = 19, 73), one- and two-knot systems, true warm start,
-    batches - and the default meets the oracle."""
+    WAVE-PRIVATE operand windows: every wave advances the halo rows of r and p itself with the owner's FMA, so an iteration has
+    the two barriers of its block sums only (the shared-window form it was checked against bit for bit in rounds 3-4 is gone).
+    Wave boundaries inside a knot (K = 19, 73), one- and two-knot systems, true warm start, batches: 12 fixed iterations against
+    the oracle's iterates, the tolerance exit against the oracle's solve, the same bits run after run, and - the halo rows are
+    where this kernel could go wrong - the general one-row-per-lane kernel on the same system beside it."""
     from gato_python_amd.solver import Solver
     S, C, dt = 14, 7, np.float32
     systems = [system(S, C, K, seed=11 + b) if K > 1 else synth.blocks_to_csr(*synth.make_blocks(S, C, 1, 11 + b, False)) for b in range(B)]
+    lam0 = np.random.default_rng(K).standard_normal(B * S * K).astype(dt)
     res = {}
-    for shared in (0, 1):
+    for no_pair in (0, 1):
+        if no_pair and B > 1 and K * S > 768:
+            continue                                    # (a batch needs one workgroup per system: the one-row kernel serves K S <= 768)
         sol = Solver(S, C, K, dt, batch=B)
-        sol.set_option("shared_windows", shared)
+        sol.set_option("no_pair", no_pair)
         if warm:
             sol.set_option("true_warm_start", 1)
         sol.set_option("record_eta", 1)
         lam, dz, it = sol.new(B * S * K), sol.new(B * sol.N), sol.new(B, torch.int32)
         dev = sol.upload_batch(systems) if B > 1 else sol.upload_system(systems[0])
         runs = []
-        for (tol, mi) in ((0.0, 12 if K > 2 else K), (1e-5, 80)):     # (a one-knot system is solved exactly by its first step: eta = 0 afterwards)
+        for (tol, mi) in ((0.0, 12 if K > 2 else K), (1e-5, 80), (1e-5, 80)):     # (a one-knot system is solved exactly by its first step: eta = 0 afterwards)
             if warm:
-                lam.copy_(torch.from_numpy(np.random.default_rng(K).standard_normal(B * S * K).astype(dt)))
+                lam.copy_(torch.from_numpy(lam0))
             if B > 1:
                 sol.linsys_batched(*dev, tol, mi, systems[0].rho, lam, dz, it)
             else:
                 sol.linsys(*dev, tol, mi, systems[0].rho, lam, dz)
             sol.check_status()
             runs.append((host(lam).copy(), host(dz).copy(), host(it).copy() if B > 1 else sol.eta_history(min(mi, 12))))
-        assert sol.get_option("last_pair") == 1 and sol.get_option("last_groups") == 1
-        res[shared] = runs
+        if not no_pair:
+            assert sol.get_option("last_pair") == 1 and sol.get_option("last_groups") == 1
+        res[no_pair] = runs
         sol.close()
-    for a, b in zip(res[0], res[1]):
-        assert np.isfinite(a[0]).all() and np.isfinite(a[1]).all()
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-    if not warm and K > 2:
-        n_dz = (S + C) * K - C
-        check_solve(f"private windows 14/7/{K} x{B} float32", systems[0], S, C, K, dt, 1e-5, 80, res[0][1][0][:S * K], res[0][1][1][:n_dz])
+    fixed, tol1, tol2 = res[0]
+    assert np.isfinite(fixed[0]).all() and np.isfinite(fixed[1]).all()
+    assert np.array_equal(tol1[0], tol2[0]) and np.array_equal(tol1[1], tol2[1]) and np.array_equal(tol1[2], tol2[2])     # deterministic
+    n_dz = (S + C) * K - C
+    if 1 in res and K > 2:          # the one-row kernel on the same inputs: another summation grouping of the same recurrence
+        assert rel(fixed[0], res[1][0][0]) < 2e-4 and rel(tol1[0], res[1][1][0]) < 2e-3, (rel(fixed[0], res[1][0][0]), rel(tol1[0], res[1][1][0]))
+    if K > 2:
+        check_solve(f"private windows 14/7/{K} x{B} float32" + (" warm start" if warm else ""), systems[0], S, C, K, dt, 1e-5, 80,
+                    tol1[0][:S * K], tol1[1][:n_dz])
+        if not warm:
+            s0 = systems[0]
+            lam_o, dz_o, _ = co.linsys_solve(*s0.csr_args(), S, C, K, 0.0, 12, s0.rho, dtype=dt)
+            s64, rho32 = _f32_truth_inputs(s0)
+            lam_t, dz_t, _ = co.linsys_solve(*s64.csr_args(), S, C, K, 0.0, 12, rho32, dtype=np.float64)
+            check_f32(f"private windows, lambda after 12 iterations 14/7/{K} x{B}", fixed[0][:S * K], lam_o, lam_t)
+            check_f32(f"private windows, dz after 12 iterations 14/7/{K} x{B}", fixed[1][:n_dz], dz_o, dz_t)
 
 
 @pytest.mark.parametrize("S,C,K,dt,B", [(14, 7, 50, np.float64, 1), (14, 7, 37, np.float64, 1), (14, 7, 50, np.float64, 6), (2, 1, 5, np.float64, 1),
@@ -1403,9 +1486,9 @@ def test_dz_in_the_pcg_epilogue_is_bit_identical_to_the_dz_launch(S, C, K, dt, B
                 two_orders=K <= 2)
 
 
-@pytest.mark.parametrize("K,B,shared", [(50, 6, 0), (50, 6, 1), (37, 3, 0), (73, 2, 0), (3, 4, 0), (1, 2, 0)])
-def test_dz_in_the_fp32_two_row_epilogue_of_a_batch_is_bit_identical_to_the_dz_launch(K, B, shared):
-    """Batches through pcg_single_f32x2_kernel (one workgroup per system, two rows per lane, wave-private or shared windows): the
+@pytest.mark.parametrize("K,B", [(50, 6), (37, 3), (73, 2), (3, 4), (1, 2)])
+def test_dz_in_the_fp32_two_row_epilogue_of_a_batch_is_bit_identical_to_the_dz_launch(K, B):
+    """Batches through pcg_single_f32x2_kernel (one workgroup per system, two rows per lane, wave-private windows): the
     dz back-substitution rides in the launch's epilogue as in the fp64 kernel - the bits of dz_kernel, no dz launch."""
     from gato_python_amd.solver import Solver
     S, C, dt = 14, 7, np.float32
@@ -1414,7 +1497,6 @@ def test_dz_in_the_fp32_two_row_epilogue_of_a_batch_is_bit_identical_to_the_dz_l
     for nofuse in (0, 1):
         sol = Solver(S, C, K, dt, batch=B)
         sol.set_option("no_fuse_dz", nofuse)
-        sol.set_option("shared_windows", shared)
         dev = sol.upload_batch(systems)
         lam, dz = sol.new(B * S * K), sol.new(B * sol.N)
         dz.fill_(float("nan"))
@@ -1436,7 +1518,7 @@ def test_dz_in_the_fp32_two_row_epilogue_of_a_batch_is_bit_identical_to_the_dz_l
         for b in (0, B - 1):
             it_o = check_solve(f"fp32 two-row epilogue dz 14/7/{K} system {b} of {B}", systems[b], S, C, K, dt, 1e-5, 60,
                                res[0][0][b * S * K:(b + 1) * S * K], res[0][1][b * n_dz:(b + 1) * n_dz], two_orders=tiny)
-            if tiny and shared == 0:
+            if tiny:
                 n = min(it_o + 5, 60)
                 sol = Solver(S, C, K, dt, batch=B)
                 dev = sol.upload_batch(systems)
@@ -1451,11 +1533,10 @@ def test_dz_in_the_fp32_two_row_epilogue_of_a_batch_is_bit_identical_to_the_dz_l
                 sol.close()
 
 
-def test_mixed_rows_kernel_both_layouts():
-    """Round 4: the one-row waves of pcg_single_f64m_kernel own 16-lane DPP rows (default; four two-row waves beside them, even
-    columns of S and Pinv in registers, odd ones in LDS) - against round 2's dense layout (option mixed_dense) on the same
-    matrices: the per-row products are the same chains, only the grouping of the dot products differs (rounding level), and
-    both stop at the oracle's iteration.  Every K the kernel serves, batches included."""
+def test_mixed_rows_kernel_every_size_it_serves():
+    """pcg_single_f64m_kernel (BASELINE configs[1]: four two-row waves + four waves of 16-lane DPP rows; round 2's dense layout it
+    was A/B-ed against for two rounds is gone): every K it serves stops at the oracle's iteration with the oracle's solution, and
+    the general launch (option no_pair) on the same matrices agrees to rounding (another grouping of the dot products)."""
     S, C = 14, 7
     for K in (37, 42, 49, 50):
         s = synth.make_system(S, C, K, seed=300 + K)
@@ -1464,13 +1545,13 @@ def test_mixed_rows_kernel_both_layouts():
         Pb = co.form_ss(Sb, Pb, S, K)
         lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, 1e-10, 300)
         res = {}
-        for dense in (0, 1):
+        for no_pair in (0, 1):
             sol = make_solver(S, C, K, np.float64)
-            sol.set_option("mixed_dense", dense)
+            sol.set_option("no_pair", no_pair)
             lam, it = sol.pcg(sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam), 1e-10, 300)
-            assert sol.get_option("last_pair") == 2 and int(host(it)[0]) == it_o, (K, dense, int(host(it)[0]), it_o)
-            assert rel(host(lam), lam_o) < 1e-10, (K, dense)
-            res[dense] = host(lam).copy()
+            assert sol.get_option("last_pair") == (0 if no_pair else 2) and int(host(it)[0]) == it_o, (K, no_pair, int(host(it)[0]), it_o)
+            assert rel(host(lam), lam_o) < 1e-10, (K, no_pair)
+            res[no_pair] = host(lam).copy()
             sol.close()
         assert rel(res[0], res[1]) < 1e-11, K
 
@@ -1575,101 +1656,3 @@ def test_multi_workgroup_solve_beside_a_long_foreign_kernel(K):
     sol.close()
 
 
-@pytest.mark.parametrize("S,C,K,dt,opts", [(14, 7, 50, np.float64, {}), (14, 7, 50, np.float32, {}),
-                                           (14, 7, 50, np.float64, dict(pcg_threads=192)),       # 10 knots per workgroup
-                                           (14, 7, 512, np.float64, {}), (14, 7, 512, np.float32, {}),
-                                           (14, 7, 4096, np.float32, {}), (14, 7, 4096, np.float64, {}),
-                                           (32, 16, 300, np.float64, {}), (32, 16, 1024, np.float32, {}),
-                                           (2, 1, 900, np.float64, dict(pcg_threads=64)), (14, 7, 3, np.float64, {})])
-def test_pipelined_variant(S, C, K, dt, opts):
-    """Opt-in pipelined recurrence (pcg_variant = 2, Ghysels-Vanroose: the dots of an iteration travel while its two
-    products run): equals its own numpy restatement (oracle.pcg_pipelined) to rounding and the reference recurrence's
-    solution to solver tolerance, iteration counts within two of each other, bitwise deterministic."""
-    s = synth.make_system(S, C, K, seed=29)
-    Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
-    Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
-    Pb = co.form_ss(Sb, Pb, S, K)
-    f64 = dt == np.float64
-    tol = 1e-9 if f64 else 1e-4
-    lam_pp, it_pp = o.pcg_pipelined(Sb, Pb, gam, S, K, tol, 300)
-    lam_ref, it_ref = co.pcg(Sb, Pb, gam, S, K, tol, 300)
-    sol = make_solver(S, C, K, dt)
-    sol.set_option("pcg_variant", 2)
-    for k, v in opts.items():
-        sol.set_option(k, v)
-    dS, dP, dg = sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam)
-    lam, it = sol.pcg(dS, dP, dg, tol, 300)
-    assert sol.get_option("last_variant") == 2
-    assert abs(int(host(it)[0]) - it_pp) <= (1 if f64 else 2), (int(host(it)[0]), it_pp, it_ref)
-    assert abs(int(host(it)[0]) - it_ref) <= 2
-    if f64:
-        assert rel(host(lam), lam_pp) < 1e-7 and rel(host(lam), lam_ref) < 1e-6, (rel(host(lam), lam_pp), rel(host(lam), lam_ref))
-        # a fixed number of iterations: the iterates themselves against the restatement
-        lam12, _ = sol.pcg(dS, dP, dg, 0.0, 12)
-        assert rel(host(lam12), o.pcg_pipelined(Sb, Pb, gam, S, K, 0.0, 12)[0]) < 1e-9
-    else:           # fp32: the converged fp64 solution of the same matrices is the truth for both recurrences
-        conv = co.pcg(Sb.astype(np.float64), Pb.astype(np.float64), gam.astype(np.float64), S, K, 1e-14, 600)[0]
-        check_f32(f"pipelined variant vs its restatement {S}/{C}/{K}", host(lam), lam_pp, conv)
-    lam1, it1 = sol.pcg(dS, dP, dg, tol, 300)
-    lam2, it2 = sol.pcg(dS, dP, dg, tol, 300)
-    assert torch.equal(lam1, lam2) and torch.equal(it1, it2)        # deterministic
-    sol.check_status()
-    sol.close()
-
-
-def test_f32_hybrid_kernel_every_size_it_serves():
-    """Round 4: fp32 one-workgroup solves of 37 <= K <= 52 knots (14/7) run four two-row waves + four DPP-row waves
-    (pcg_single_f32h_kernel, option f32_hybrid: opt-in, measured equal in time) instead of five or six two-row waves.  Per-row products are the same chains as in the two-row
-    kernel (option no_hybrid), the dot products group differently: against the oracle by check_f32, against the two-row
-    kernel at rounding level, whole solves with the helper blocks' dz, batches and the true warm start included."""
-    from gato_python_amd.solver import Solver
-    S, C = 14, 7
-    for K in (37, 41, 44, 50, 52):
-        s = synth.make_system(S, C, K, seed=500 + K)
-        Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, np.float32)
-        Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
-        Pb = co.form_ss(Sb, Pb, S, K)
-        res = {}
-        for nh in (0, 1):
-            sol = make_solver(S, C, K, np.float32)
-            sol.set_option("f32_hybrid", 1 - nh)
-            dS, dP, dg = sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam)
-            lam12, _ = sol.pcg(dS, dP, dg, 0.0, 12)
-            check_pcg(f"f32 hybrid={1 - nh} 14/7/{K} 12 iterations", Sb, Pb, gam, S, K, 0.0, 12, host(lam12))
-            lam, it = sol.pcg(dS, dP, dg, 1e-4, 300)
-            check_pcg(f"f32 hybrid={1 - nh} 14/7/{K} to 1e-4", Sb, Pb, gam, S, K, 1e-4, 300, host(lam), int(host(it)[0]))
-            lam2, it2 = sol.pcg(dS, dP, dg, 1e-4, 300)
-            assert torch.equal(lam, lam2) and torch.equal(it, it2)          # deterministic
-            assert sol.get_option("last_pair") == 1 and sol.get_option("last_groups") == 1
-            res[nh] = (host(lam12).copy(), int(host(it)[0]))
-            if nh == 0 and K in (37, 50):                                   # true warm start through the hybrid
-                sol.set_option("true_warm_start", 1)
-                lam_o, it_o = o.pcg(Sb.astype(np.float64), Pb.astype(np.float64), gam.astype(np.float64), S, K, 1e-12, 300)
-                l0 = (lam_o * (1 + 1e-3 * np.cos(np.arange(S * K)))).astype(np.float32)
-                lam_w, it_w = o.pcg(Sb, Pb, gam, S, K, 1e-4, 300, lam0=l0)
-                lamw, itw = sol.pcg(dS, dP, dg, 1e-4, 300, lam=sol.to_device(l0))
-                assert abs(int(host(itw)[0]) - it_w) <= 2 and rel(host(lamw), lam_o) < 1e-3, (K, int(host(itw)[0]), it_w)
-            sol.close()
-        assert rel(res[0][0], res[1][0]) < 2e-5 and abs(res[0][1] - res[1][1]) <= 1, (K, rel(res[0][0], res[1][0]), res[0][1], res[1][1])
-        # whole solve (assembly images, helper blocks' dz) and a small batch
-        sol = Solver(S, C, K, np.float32)
-        sol.set_option("f32_hybrid", 1)
-        dev = sol.upload_system(s)
-        lam, dz = sol.new(S * K), sol.new(sol.N)
-        dz.fill_(float("nan"))
-        sol.linsys(*dev, 1e-5, 100, s.rho, lam, dz)
-        torch.cuda.synchronize(); sol.check_status()
-        check_solve(f"f32 hybrid whole solve 14/7/{K}", s, S, C, K, np.float32, 1e-5, 100, host(lam), host(dz))
-        sol.close()
-    K, B = 50, 5
-    systems = [synth.make_system(S, C, K, seed=700 + b) for b in range(B)]
-    sol = Solver(S, C, K, np.float32, batch=B)
-    sol.set_option("f32_hybrid", 1)
-    dev = sol.upload_batch(systems)
-    lam, dz, it = sol.new(B * S * K), sol.new(B * sol.N), sol.new(B, torch.int32)
-    sol.linsys_batched(*dev, 1e-5, 100, systems[0].rho, lam, dz, it)
-    torch.cuda.synchronize(); sol.check_status()
-    for b, sysm in enumerate(systems):
-        check_solve(f"f32 hybrid batch system {b}", sysm, S, C, K, np.float32, 1e-5, 100, host(lam)[b * S * K:(b + 1) * S * K],
-                    host(dz)[b * sol.N:(b + 1) * sol.N])
-    sol.close()

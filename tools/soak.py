@@ -18,11 +18,8 @@ for (S, C, K, dt, opts) in [(14, 7, 512, np.float32, {}), (14, 7, 1024, np.float
                             (14, 7, 700, np.float64, dict(pcg_threads=256)), (14, 7, 50, np.float64, {}), (14, 7, 41, np.float64, {}),
                             (14, 7, 50, np.float32, {}), (14, 7, 73, np.float32, {}), (14, 7, 19, np.float32, {}), (14, 7, 37, np.float32, {}),   # helper blocks do dz; fp32: wave-private windows, transposed images
                             (14, 7, 20000, np.float32, {}), (14, 7, 15000, np.float64, {}),     # semi-resident launches
-                            # round 4: pipelined recurrence (publishes the next iteration's partials before the barrier), runtime co-residency,
-                            # fp32 hybrid one-workgroup kernel, the smallest K of the mixed-rows fp64 kernel, fp64 LDS-DMA ring
-                            (14, 7, 4096, np.float32, dict(pcg_variant=2)), (14, 7, 512, np.float32, dict(pcg_variant=2)), (14, 7, 4096, np.float64, dict(pcg_variant=2)),
-                            (14, 7, 4096, np.float32, dict(coop_launch=1)), (14, 7, 50, np.float32, dict(f32_hybrid=1)), (14, 7, 33, np.float64, {}),
-                            (14, 7, 65536, np.float64, dict(pcg_semi=3))]:
+                            # round 4: runtime co-residency, the smallest K of the mixed-rows fp64 kernel, fp64 LDS-DMA ring (auto since round 5)
+                            (14, 7, 4096, np.float32, dict(coop_launch=1)), (14, 7, 33, np.float64, {}), (14, 7, 65536, np.float64, {})]:
     s = synth.make_system(S, C, K, seed=3)
     sol = Solver(S, C, K, dt)
     for k_, v in opts.items():
