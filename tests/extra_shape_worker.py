@@ -29,7 +29,8 @@ def main():
             for batch in ((1, 3) if K <= 64 else (1,)):
                 f64 = dt == np.float64
                 tol, mi = (1e-9, 200) if f64 else (1e-4, 80)
-                systems = [synth.make_system(S, C, K, seed=40 + b) for b in range(batch)]
+                systems = [synth.make_system(S, C, K, seed=40 + b) if K > 1 else synth.blocks_to_csr(*synth.make_blocks(S, C, 1, 40 + b, False))
+                           for b in range(batch)]
                 sol = Solver(S, C, K, dt, batch=batch)
                 lam, dz = sol.new(batch * S * K), sol.new(batch * sol.N)
                 if batch == 1:
