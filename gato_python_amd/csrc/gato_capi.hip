@@ -875,13 +875,10 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
 {
     int groups = 0, threads = 0, kpw = 0;
     int mode = s->pcg_mode;
-    // pcg_variant: 1 = single-reduction recurrence (opt-in): where the default launch would be the fp64 one-workgroup mixed-rows
-    // kernel (BASELINE configs[1] and its batches), that kernel's own single-reduction form (cg1_single: same layout, one block sum
-    // and three barriers per iteration); elsewhere the general kernel of gato_pcg_cg1.hip
-    const bool want_cg1 = s->pcg_variant == 1 && mode != GATO_PCG_STREAMING && !s->true_warm_start;
-    const bool cg1_single = want_cg1 && plan_resident(s, &groups, &threads, &kpw) != 0 && s->plan_pair == 2;
-    const bool cg1 = want_cg1 && !cg1_single && plan_cg1(s, &groups, &threads, &kpw) != 0 && (batch == 1 || groups == 1);
-    const bool fits = cg1 || cg1_single || plan_resident(s, &groups, &threads, &kpw) != 0;
+    // pcg_variant: 1 = single-reduction recurrence (opt-in, gato_pcg_cg1.hip)
+    const bool cg1 = s->pcg_variant == 1 && mode != GATO_PCG_STREAMING && !s->true_warm_start &&
+                     plan_cg1(s, &groups, &threads, &kpw) != 0 && (batch == 1 || groups == 1);
+    const bool fits = cg1 || plan_resident(s, &groups, &threads, &kpw) != 0;
     if (cg1) s->plan_pair = 0;
     if (mode == GATO_PCG_AUTO) mode = fits ? GATO_PCG_RESIDENT : GATO_PCG_STREAMING;
     if (mode == GATO_PCG_RESIDENT) {
@@ -911,7 +908,6 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.batch = batch;
         a.pair = s->plan_pair;
         a.coop = s->coop_launch && groups > 1 && batch == 1 && !cg1;      // (the single-reduction kernel keeps the plain launch)
-        a.cg1 = cg1_single;
         // (every lane of the launch loads rows 2 tid, 2 tid + 1 resp. its own row: all of them must lie inside a column of the image)
         if (s->img_fresh && !s->no_image && batch == 1 && d_S == s->Sbd && d_Pinv == s->Pbd &&
             ((s->plan_pair == 1 && 2 * threads <= s->img_ld) || (s->plan_pair == 2 && s->plan.mixed_rows <= s->img_ld))) {
@@ -973,7 +969,7 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.ev_start = s->time_pcg ? s->ev_pcg0 : nullptr;
         a.ev_stop = s->time_pcg ? s->ev_pcg1 : nullptr;
         s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT;
-        s->last_variant = (cg1 || cg1_single) ? 1 : 0;
+        s->last_variant = cg1 ? 1 : 0;
         s->last_semi = a.semi;
         s->last_stream = st;
         // co-residency: a multi-workgroup launch waits for launches on other streams it would not fit beside

@@ -211,7 +211,6 @@ struct PcgLaunch {
     unsigned long long *stamps;        // optional: diagnostic cycle stamps (16 words), selects the DIAG = 1 build
     int diag;                          // 2: the build with the timing-only switches (ablate) but no stamps
     int coop;                          // multi-workgroup persistent launches through hipLaunchCooperativeKernel (option coop_launch)
-    int cg1;                           // fp64 one-workgroup mixed-rows kernel (pair = 2): the single-reduction recurrence (option pcg_variant = 1)
 };
 
 // Cross-GPU mirror of a cluster launch, per epoch parity (granules): one 128-B line per rank for its total (written by

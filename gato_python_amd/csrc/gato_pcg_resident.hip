@@ -1604,23 +1604,29 @@ __device__ __forceinline__ void pin_reads_then_fmas()
 #ifndef GATO_F64M_DEV_ABL
 #define GATO_F64M_DEV_ABL 0   // A/B builds only (tools/devbuild.sh -DGATO_F64M_DEV_ABL=8: the loop without its two window barriers, timing only)
 #endif
+// VERDICT r4 #3 route (ii), A/B builds only (K = 50): the two WINDOW barriers of the default recurrence replaced by neighbour-wave
+// synchronisation - a product reads window entries of its own and the adjacent waves only, so a wave bumps an LDS epoch word
+// after its window entries are written (s_waitcnt lgkmcnt(0)) and polls the two neighbouring waves' words.  Measured: see
+// DESIGN_LOG.md R5.3 (two dependent LDS round trips cost more than s_waitcnt + s_barrier).
+#ifndef GATO_F64M_NBSYNC
+#define GATO_F64M_NBSYNC 0
+#endif
 #ifndef GATO_F64M_D0
 #define GATO_F64M_D0 8      // reads in flight: two-row lanes, S product (21 reads, 84 FMAs)
 #endif
 #ifndef GATO_F64M_D2
 #define GATO_F64M_D2 8      // two-row lanes, Pinv product (60 or 63 reads, 84 FMAs)
 #endif
-// CG1 (round 5, VERDICT r4 #3 route (i)): the SINGLE-REDUCTION recurrence (Chronopoulos-Gear; opt-in, option pcg_variant = 1 - the
-// recurrence of gato_pcg_cg1.hip, restated in oracle.pcg_single_reduction) in this kernel's layout:
-//     u = Pinv r ; w = S u ; gamma' = r.u ; delta = w.u     -> ONE block sum of two values
-//     beta = gamma'/gamma ; alpha = gamma' / (delta - beta gamma'/alpha) ; p = u + beta p ; s = w + beta s ; lambda += alpha p ; r -= alpha s
-// An iteration of the default recurrence is product | block sum | update, window | barrier | product | block sum | update, window |
-// barrier - four barriers and two dependent block-sum chains (0.31 + 0.45 us of its 1.54: the serial part that did not move in
-// round 4).  Here: window r | barrier | product | window u | barrier | product | block sum - three barriers, one chain.  That needs
-// TWO operand windows (u is written while slower waves still read r): their 5.8 KB come from two more Pinv column pairs in
-// registers (NPR = 3 instead of 1: 8 VGPRs).  Not the reference's recurrence (rounding differs, iteration count may move by one):
-// the default stays the default.
-template <int S, int W2, int WT, int ABL = 0, int K2MAX = 0, int NPR = 0, bool CG1 = false>
+// Round 5, VERDICT r4 #3 - both routes measured, neither kept (profiles/r05_headline_experiments.log, r05_f64m_stamps.log; DESIGN_LOG.md R5.3):
+//  (i) the SINGLE-REDUCTION recurrence in this layout (one block sum of two values, three barriers, a second operand window paid
+//      for by two more Pinv pairs in registers): 2.36 us per iteration with all vectors in registers (256 VGPRs: the products'
+//      landing registers are gone and their LDS reads run two at a time), 1.75 with r and u re-read from the windows, 1.70 with
+//      them live between the products only - against 1.55 for the default recurrence.  This layout has 12 registers to spare;
+//      the recurrence needs 16 more.  pcg_variant = 1 at this shape therefore stays with the general kernel of gato_pcg_cg1.hip.
+//  (ii) neighbour-wave synchronisation instead of the two window barriers (GATO_F64M_NBSYNC below): 1.684 against 1.555 - two
+//      dependent LDS round trips (flag write -> visible -> poll) cost more than s_waitcnt + s_barrier (188 / 120 cycles in the
+//      stamps, of which ~100 are the window write's own latency).
+template <int S, int W2, int WT, int ABL = 0, int K2MAX = 0, int NPR = 0>
 __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 {
     typedef double T;
@@ -1637,12 +1643,11 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
     // behind the other's last read (the block sum's), so the two never meet - and a second window's 5.8 KB are what lets the
     // Pinv pairs of 238 two-row lanes fit the LDS with only NPR of them in registers
     __shared__ __attribute__((aligned(16))) T xs[(MAXK + 2) * SP];
-    __shared__ __attribute__((aligned(16))) T xs2[CG1 ? (MAXK + 2) * SP : 2];      // CG1: the u window beside the r window
     constexpr int WPW = WT < 8 ? 8 : WT;                                           // partials_total_all8 reads eight waves' slots (zeros beyond WT)
     __shared__ __attribute__((aligned(32))) T wpart[2][4 * WPW];
     static_assert(WT > 8 || sizeof(wpart) / 2 >= 32 * sizeof(T), "partials_total_all8 reads 32 values per buffer");
     __shared__ __attribute__((aligned(16))) V2 ptail[NC][LSTR];                    // Pinv entry NPR + c of (row a, row b) of a two-row lane
-    static_assert(sizeof(xs) + sizeof(xs2) + sizeof(wpart) + sizeof(ptail) <= 160 * 1024, "LDS of one CU");
+    static_assert(sizeof(xs) + sizeof(wpart) + sizeof(ptail) <= 160 * 1024, "LDS of one CU");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool two = __builtin_amdgcn_readfirstlane(wave) < W2;                    // wave-uniform and known as such: scalar branches
@@ -1768,8 +1773,6 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         }
     }
     for (int i = tid; i < (MAXK + 2) * SP; i += NT) xs[i] = (T)0;
-    if constexpr (CG1)
-        for (int i = tid; i < (MAXK + 2) * SP; i += NT) xs2[i] = (T)0;
     for (int i = tid; i < 2 * 4 * WPW; i += NT) (&wpart[0][0])[i] = (T)0;
     __syncthreads();
 
@@ -1873,50 +1876,25 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
     int iters = a.max_iters;
     const T tol = (T)a.exit_tol;
     T eta = (T)0, eta_new = (T)0;
-    if constexpr (CG1) {
-        // one block sum of two values: the two partial buffers side by side (a buffer is reused one iteration - three barriers -
-        // later: no parity), the second level of both in flight together
-        auto block_sum2 = [&](T d0, T d1, T &t0, T &t1) {
-            partials_store(wpart[0], wave, lane, d0);
-            partials_store(wpart[1], wave, lane, d1);
-            __syncthreads();
-            if constexpr (WT <= 8) { t0 = partials_total_all8<T>(wpart[0], lane); t1 = partials_total_all8<T>(wpart[1], lane); }
-            else { t0 = partials_total<T, 16>(wpart[0], WT, lane); t1 = partials_total<T, 16>(wpart[1], WT, lane); }
-        };
-        const T *wu_ = &xs2[j * SP];
-        V2 p = {0, 0}, sv = {0, 0}, u, w;
-        T gam = (T)0, delta = (T)0, alpha = (T)0, beta = (T)0;
-        put(xs, r);
-        __syncthreads();
-        u = times_window(1, wr_, r);                                             // u = Pinv r
-        put(xs2, u);
-        __syncthreads();
-        w = times_window(0, wu_, u);                                             // w = S u
-        block_sum2(r[0] * u[0] + r[1] * u[1], w[0] * u[0] + w[1] * u[1], gam, delta);
-        if (rec) a.eta_hist[0] = (double)gam;
-        alpha = quotient(gam, delta);
-        eta_new = gam;
-        for (int it = 0; it < a.max_iters; ++it) {
-            p = u + beta * p;
-            sv = w + beta * sv;
-            lam += alpha * p;
-            r -= alpha * sv;
-            put(xs, r);                                  // (the last reads of this window: the Pinv product two barriers ago)
-            __syncthreads();
-            u = times_window(1, wr_, r);
-            put(xs2, u);                                 // (its last reads: the S product in front of the block sum's barrier)
-            __syncthreads();
-            w = times_window(0, wu_, u);
-            T gam_new;
-            block_sum2(r[0] * u[0] + r[1] * u[1], w[0] * u[0] + w[1] * u[1], gam_new, delta);
-            eta_new = gam_new;
-            if (rec) a.eta_hist[it + 1] = (double)gam_new;
-            if (__builtin_amdgcn_readfirstlane((int)(fabs(gam_new) < tol))) { iters = it; break; }   // the reference's test quantity, gato_pcg.cuh:404
-            beta = quotient(gam_new, gam);
-            alpha = quotient(gam_new, delta - quotient(beta * gam_new, alpha));
-            gam = gam_new;
+#if GATO_F64M_NBSYNC
+    __shared__ unsigned nb_flag[WT + 2];                       // [w + 1] = wave w's epoch; [0], [WT + 1]: always current
+    if (tid < WT + 2) nb_flag[tid] = (tid == 0 || tid == WT + 1) ? 0xffffffffu : 0u;
+    __syncthreads();
+    unsigned nb_seq = 0;
+    auto window_sync = [&]() {
+        ++nb_seq;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's window entries are written
+        volatile unsigned *f = nb_flag;
+        if (lane == 0) f[wave + 1] = nb_seq;
+        for (;;) {
+            const unsigned l = f[wave], r_ = f[wave + 2];
+            if (l >= nb_seq && r_ >= nb_seq) break;
         }
-    } else {
+        asm volatile("" ::: "memory");
+    };
+#else
+    auto window_sync = [&]() { __syncthreads(); };
+#endif
     put(xs, r);
     __syncthreads();
     V2 rt = times_window(1, wr_, r);                                             // gato_pcg.cuh:316-335
@@ -1939,7 +1917,7 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         r -= alpha * ups;
         put(xs, r);
         GATO_ST(5);
-        if (!(abl & 8)) __syncthreads();
+        if (!(abl & 8)) window_sync();
         GATO_ST(6);
         rt = (abl & 2) ? r * m[1] : times_window(1, wr_, r);                     // r~ = Pinv r           (:380-381)
         GATO_ST(7);
@@ -1952,9 +1930,8 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
         put(xs, p);
         eta = eta_new;                                                           // :420
         GATO_ST(11);
-        if (!(abl & 8)) __syncthreads();
+        if (!(abl & 8)) window_sync();
         GATO_ST(12);
-    }
     }
 #ifdef GATO_F64M_STAMP
     if (a.eta_hist && lane == 0 && sys == 0)
@@ -2042,9 +2019,8 @@ __global__ __launch_bounds__(64 * WT) void pcg_single_f64m_kernel(PcgLaunch a)
 
 // shape of the mixed kernel per STATE_SIZE (0 = none): waves with two rows per lane, waves in all (the others own 16-lane DPP rows,
 // one knot each), k2 = knots the two-row lanes can take (LDS), npr = their Pinv columns in registers
-// (npr_cg1: the single-reduction form keeps two more Pinv column pairs in registers - their LDS is its second operand window)
-template <int S> struct MixedCfg { static constexpr int w2 = 0, wt = 0, k2 = 0, npr = 0, npr_cg1 = 0; };
-template <> struct MixedCfg<14> { [[maybe_unused]] static constexpr int w2 = 4, wt = 8, k2 = 34, npr = 1, npr_cg1 = 3; };   // 34 + 4 x 4 = 50 knots
+template <int S> struct MixedCfg { static constexpr int w2 = 0, wt = 0, k2 = 0, npr = 0; };
+template <> struct MixedCfg<14> { [[maybe_unused]] static constexpr int w2 = 4, wt = 8, k2 = 34, npr = 1; };   // 34 + 4 x 4 = 50 knots
 template <int S> constexpr int mixed_rows()
 {
     if (MixedCfg<S>::wt <= 0) return 0;
@@ -2297,7 +2273,7 @@ int launch_pcg_single(const PcgLaunch &a, bool mr, hipStream_t st)
     if constexpr (sizeof(T) == 8 && MixedCfg<S>::wt > 0) {
         if (a.pair == 2) {
             constexpr int W2 = MixedCfg<S>::w2, WT = MixedCfg<S>::wt, K2 = MixedCfg<S>::k2, NPR = MixedCfg<S>::npr;
-            if (mr || a.groups != 1 || a.threads != 64 * WT || a.K * S > mixed_rows<S>() || a.stamps || (a.cg1 && a.lambda0)) {
+            if (mr || a.groups != 1 || a.threads != 64 * WT || a.K * S > mixed_rows<S>() || a.stamps) {
                 set_error("pcg_resident(mixed): bad launch K=%d threads=%d", a.K, a.threads);
                 return GATO_EINVAL;
             }
@@ -2308,7 +2284,6 @@ int launch_pcg_single(const PcgLaunch &a, bool mr, hipStream_t st)
             if (abl == 3) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 3, K2, NPR>), grid, block, 0, st, a);
             else if (abl == 4) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 4, K2, NPR>), grid, block, 0, st, a);
             else if (abl == 15) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 15, K2, NPR>), grid, block, 0, st, a);
-            else if (a.cg1) hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, 0, K2, MixedCfg<S>::npr_cg1, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((pcg_single_f64m_kernel<S, W2, WT, GATO_F64M_DEV_ABL, K2, NPR>), grid, block, 0, st, a);
             GATO_HIP_CHECK(hipGetLastError());
             if (a.ev_stop) GATO_HIP_CHECK(hipEventRecord(a.ev_stop, st));

@@ -1556,63 +1556,6 @@ def test_mixed_rows_kernel_every_size_it_serves():
         assert rel(res[0], res[1]) < 1e-11, K
 
 
-def test_mixed_rows_kernel_single_reduction_form():
-    """option pcg_variant = 1 at BASELINE configs[1]'s shape runs pcg_single_f64m_kernel<..., CG1> - the
-    single-reduction recurrence in the mixed-rows layout (one block sum of two values and three barriers per iteration; two operand
-    windows) - not the general kernel.  Against its restatement (oracle.pcg_single_reduction: iteration count, lambda to
-    rounding, eta history), the reference recurrence's solution to solver tolerance, whole solves (dz by the helper blocks) and
-    batches (dz in the epilogue; the bits of the one-system launches)."""
-    from gato_python_amd.solver import Solver
-    S, C, dt = 14, 7, np.float64
-    for K in (37, 42, 50):
-        s = synth.make_system(S, C, K, seed=310 + K)
-        Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
-        Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
-        Pb = co.form_ss(Sb, Pb, S, K)
-        lam_cg, it_cg = o.pcg_single_reduction(Sb, Pb, gam, S, K, 1e-10, 300)
-        lam_ref, it_ref = co.pcg(Sb, Pb, gam, S, K, 1e-10, 300)
-        sol = make_solver(S, C, K, dt)
-        sol.set_option("pcg_variant", 1)
-        sol.set_option("record_eta", 1)
-        dS, dP, dg = sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam)
-        lam, it = sol.pcg(dS, dP, dg, 1e-10, 300)
-        n = int(host(it)[0])
-        assert sol.get_option("last_variant") == 1 and sol.get_option("last_pair") == 2 and sol.get_option("last_groups") == 1
-        assert n == it_cg and abs(n - it_ref) <= 1, (K, n, it_cg, it_ref)
-        assert rel(host(lam), lam_cg) < 1e-9 and rel(host(lam), lam_ref) < 1e-7, (K, rel(host(lam), lam_cg), rel(host(lam), lam_ref))
-        h = sol.eta_history(n + 1)
-        assert np.all(np.isfinite(h)) and abs(h[n + 1]) < 1e-10 <= abs(h[n])
-        lam2, it2 = sol.pcg(dS, dP, dg, 1e-10, 300)
-        assert torch.equal(lam, lam2) and torch.equal(it, it2)                  # deterministic
-        # whole solve: assembly + this launch (+ dz by its helper blocks) against the oracle's whole solve (reference recurrence)
-        dev = sol.upload_system(s)
-        lw, dz = sol.new(S * K), sol.new(sol.N)
-        dz.fill_(float("nan"))
-        sol.linsys(*dev, 1e-12, 300, s.rho, lw, dz)
-        sol.check_status()
-        assert sol.get_option("last_variant") == 1 and sol.get_option("last_dz_fused") == 2
-        lam_o, dz_o, _ = co.linsys_solve(*s.csr_args(), S, C, K, 1e-12, 300, s.rho, dtype=dt)
-        assert rel(host(lw), lam_o) < 1e-8 and rel(host(dz), dz_o) < 1e-8
-        one = (host(lw).copy(), host(dz).copy())
-        sol.close()
-        if K == 50:
-            B = 3
-            bs = Solver(S, C, K, dt, batch=B)
-            bs.set_option("pcg_variant", 1)
-            systems = [s, synth.make_system(S, C, K, seed=999), s]
-            devb = bs.upload_batch(systems)
-            lb, db = bs.new(B * S * K), bs.new(B * bs.N)
-            bs.linsys_batched(*devb, 1e-12, 300, s.rho, lb, db)
-            bs.check_status()
-            assert bs.get_option("last_variant") == 1 and bs.get_option("last_pair") == 2 and bs.get_option("last_dz_fused") == 1
-            hl, hd = host(lb).reshape(B, -1), host(db).reshape(B, -1)
-            for b in (0, 2):
-                assert np.array_equal(hl[b], one[0]) and np.array_equal(hd[b], one[1]), b
-            lam_o1, dz_o1, _ = co.linsys_solve(*systems[1].csr_args(), S, C, K, 1e-12, 300, systems[1].rho, dtype=dt)
-            assert rel(hl[1], lam_o1) < 1e-8 and rel(hd[1], dz_o1) < 1e-8
-            bs.close()
-
-
 def test_captured_whole_solve_replays_with_new_inputs():
     """a whole solve captured into a graph and REPLAYED after the inputs changed in place.  A replay repeats the
     launch arguments of the capture, so while a stream is being captured the helper blocks of the one-workgroup kernels do not
