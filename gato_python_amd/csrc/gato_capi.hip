@@ -907,7 +907,8 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         a.K = s->d.K; a.max_iters = max_iters; a.exit_tol = exit_tol;
         a.batch = batch;
         a.pair = s->plan_pair;
-        a.coop = s->coop_launch && groups > 1 && batch == 1 && !cg1;      // (the single-reduction kernel keeps the plain launch)
+        // (the single-reduction kernel and the LDS-DMA ring keep the plain launch: option coop_launch serves the resident / semi-resident launches)
+        a.coop = s->coop_launch && groups > 1 && batch == 1 && !cg1 && s->plan_semi != 3;
         // (every lane of the launch loads rows 2 tid, 2 tid + 1 resp. its own row: all of them must lie inside a column of the image)
         if (s->img_fresh && !s->no_image && batch == 1 && d_S == s->Sbd && d_Pinv == s->Pbd &&
             ((s->plan_pair == 1 && 2 * threads <= s->img_ld) || (s->plan_pair == 2 && s->plan.mixed_rows <= s->img_ld))) {

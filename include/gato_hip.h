@@ -81,20 +81,20 @@ void *gato_solver_buffer(gato_solver *s, int which);
  * kernel), pcg_groups (0 = auto; workgroups of the resident kernel), true_warm_start (0 = the
  * reference's behaviour: lambda restarts from zero, gato_pcg.cuh:303; 1 = d_lambda of gato_pcg /
  * gato_linsys_device is read as the initial guess, r0 = gamma - S lambda0), pcg_variant (0 = the reference's PCG
- * recurrence; 1 = opt-in single-reduction Chronopoulos-Gear recurrence of the resident kernel: one inter-workgroup
- * hand-off per iteration instead of two, same solution to solver tolerance, different rounding; 2 = opt-in pipelined
- * recurrence (Ghysels-Vanroose): the two dots of an iteration are published before its two products and collected after
- * them - measured no faster than 1 on MI355X, see gato_pcg_cg1.hip), coop_launch (1 = the multi-workgroup persistent
- * launches through hipLaunchCooperativeKernel - what the reference does, gato_pcg.cuh:502-526 - so that the runtime guarantees
- * their co-residency beside kernels of other streams and processes; +17 us per launch, default 0), mixed_dense / f32_hybrid
- * (A/B switches of the one-workgroup kernels' lane layouts), xcd_pack (-1 auto:
+ * recurrence; 1 = opt-in single-reduction Chronopoulos-Gear recurrence of the multi-workgroup and the cluster launches: one
+ * inter-workgroup / cross-GPU exchange per iteration instead of two, same solution to solver tolerance, different rounding),
+ * coop_launch (1 = the multi-workgroup resident / semi-resident launches through hipLaunchCooperativeKernel - what the
+ * reference does, gato_pcg.cuh:502-526 - so that the runtime guarantees their co-residency beside kernels of other streams
+ * and processes; +17 us per launch, default 0; the single-reduction kernel and the LDS-DMA ring keep the plain launch),
+ * xcd_pack (-1 auto:
  * launches of up to 32 workgroups are placed on one XCD - a placement hint, never needed for correctness; 0 off),
  * xcd_sel (which of the eight XCDs hosts such a launch: -1 = measured once per solver and geometry with a millisecond of
  * trial launches before the first one, 0..7 fixed; read-only last_xcd_sel),
  * asm_mode (whole-solve entries: 0 = auto - convert + Schur + stair as ONE fused launch when K*B <= 2 x CUs, the
  * stage kernels otherwise; 1 = stage kernels; 2 = fused; both give bit-identical buffers), pcg_semi (-1 = auto: K
  * beyond the register file runs as one persistent launch - semi-resident, or with the block rows streamed through an
- * LDS-DMA ring once fp32 matrices are far beyond the Infinity Cache; 0 = the streaming kernels; 1 / 2 / 3 force the
+ * LDS-DMA ring once the matrices one launch streams are far beyond the Infinity Cache (measured cross-overs: 450 MB of S + Pinv
+ * in fp32, 550 MB in fp64, 700 MB at STATE_SIZE 32); 0 = the streaming kernels; 1 / 2 / 3 force the
  * semi-resident launch with / without resident rows / the LDS-DMA ring), time_pcg (record
  * hipEvents around the PCG launch), time_stages (hipEvents around assembly / PCG / dz of the whole-solve entries),
  * precon_mode (GATO_PRECON_*), knot_lo / knot_hi (the stage-level entries gato_convert / gato_form_schur / gato_form_ss /

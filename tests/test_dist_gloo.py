@@ -32,6 +32,20 @@ def test_sharded_pcg_gloo(world, S, C, K, tol, mi, chk):
     assert r.stdout.count(" ok iters=") == world
 
 
+@pytest.mark.parametrize("world,S,C,K", [(2, 14, 7, 16), (3, 14, 7, 11), (2, 2, 1, 2), (3, 2, 1, 3)])
+def test_gather_plan_gloo(world, S, C, K):
+    """What follows a sharded solve on N > 1 ranks (linsys_solve_cluster): every rank's lambda / dz rows onto all ranks by ONE
+    all-gather of fixed-size records into preallocated buffers - equal and ragged knot ranges, the last rank's shorter dz
+    slice, the ghost lambda block behind a rank's slice left out."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
+           os.path.join(ROOT, "tests", "gather_worker.py"), str(S), str(C), str(K)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count(" ok gather ") == world
+
+
 def test_knot_ranges():
     assert knot_ranges(4096, 8) == [(i * 512, (i + 1) * 512) for i in range(8)]
     assert knot_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]

@@ -205,6 +205,36 @@ def test_cluster_neighbouring_ranks_on_different_launch_variants():
         x.close()
 
 
+def test_cluster_launch_refuses_stream_capture():
+    """a cluster launch draws its hand-off epochs per launch - captured into a graph it would be replayed with stale
+    ones - so gato_cluster_pcg refuses a capturing stream like the multi-workgroup launches of one GPU do."""
+    from gato_python_amd.dist import ClusterPCG
+    from gato_python_amd.solver import Solver
+    S, C, K, R, dt = 14, 7, 64, 2, np.float64
+    Sb, Pb, gam = oracle_blocks(S, C, K, dt)
+    sols = [Solver(S, C, K, dt) for _ in range(R)]
+    cl = [ClusterPCG(x, r, R, inprocess_peers=True) for r, x in enumerate(sols)]
+    ClusterPCG.connect_inprocess(cl)
+    dS, dP, dg = sols[0].to_device(Sb), sols[0].to_device(Pb), sols[0].to_device(gam)
+    lam = torch.zeros(S * K, dtype=torch.float64, device="cuda")
+    it = torch.zeros(1, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        g.capture_begin()
+        try:
+            with pytest.raises(_lib.GatoError, match="captured"):
+                cl[0].pcg(dS, dP, dg, 1e-9, 50, lam, it, stream=st.cuda_stream)
+        finally:
+            g.capture_end()
+    torch.cuda.synchronize()
+    for c in cl:
+        c.close()
+    for x in sols:
+        x.close()
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
