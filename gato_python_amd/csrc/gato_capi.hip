@@ -1791,6 +1791,26 @@ extern "C" int gato_cluster_linsys(gato_solver *s, const int *d_G_row, const int
     int rc;
     const bool ts = s->time_stages != 0;
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[0], st));
+    // small shards (what K = 4096 over 8 GPUs gives): ONE fused launch, a workgroup per knot, as the one-GPU whole solve takes for
+    // small systems (asm_mode: 0 = auto by the same rule, 1 = stage kernels, 2 = fused).  The workgroup of knot k writes S[k].left /
+    // .main, S[k-1].right, Pinv[k].main / .left, Pinv[k-1].right, gamma_k, the inverses of knot k and [A | B] of knot k-1: rows
+    // k0-h .. k1-1+h of S / Pinv complete, gamma on k0-1-h .. k1+h and everything dz reads on [k0, k1) come from the workgroups of
+    // the knots [k0-1-h, k1+1+h).  Bit-identical to the stage kernels (test_fused_assembly_is_bit_identical_to_the_stage_kernels).
+    const int span = clip(k1 + 1 + h) - clip(k0 - 1 - h);
+    const bool fused = s->asm_mode == 2 || (s->asm_mode == 0 && span <= 2 * s->num_cus);
+    s->last_asm_fused = fused;
+    if (fused) {
+        AsmArgs aa;
+        memset(&aa, 0, sizeof(aa));
+        aa.mode = 0;
+        aa.G_row = d_G_row; aa.G_col = d_G_col; aa.G_val = d_G_val; aa.C_row = d_C_row; aa.C_col = d_C_col; aa.C_val = d_C_val;
+        aa.rho = rho; aa.g = d_g; aa.c = d_c;
+        aa.Gd = s->G_dense; aa.Cd = s->C_dense; aa.Ginv = s->Ginv; aa.Sbd = s->Sbd; aa.Pbd = s->Pbd; aa.gamma = s->gamma;
+        range(k0 - 1 - h, k1 + 1 + h);
+        rc = s->ops->assemble(s->d, aa, st);
+        s->d.k_lo = s->d.k_hi = 0;
+        if (rc) return rc;
+    } else {
     range(k0 - 2 - h, k1 + 1 + h);
     rc = s->ops->convert(s->d, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, rho, s->G_dense, s->C_dense, nullptr, st);
     // (form_schur inverts the Q_k, R_k of its knot range first and then runs the Schur steps on the same range: the step of the
@@ -1799,6 +1819,7 @@ extern "C" int gato_cluster_linsys(gato_solver *s, const int *d_G_row, const int
     if (!rc) { range(k0 - h, k1 + h); rc = s->ops->form_ss(s->d, s->Sbd, s->Pbd, st); }
     s->d.k_lo = s->d.k_hi = 0;
     if (rc) return rc;
+    }
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[1], st));
     if ((rc = gato_cluster_pcg(s, s->Sbd, s->Pbd, s->gamma, d_lambda, exit_tol, max_iters, d_iters, stream))) return rc;
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[2], st));

@@ -112,7 +112,9 @@ __device__ __forceinline__ bool cluster_lambda_ghost(const PcgLaunch &a, int wg,
     __syncthreads();                                    // the workgroup's lambda rows are stored (block 0 by lanes of any wave)
     bool ok = true;
     if (wg == 0 && a.rank > 0 && tid < S) {
-        const T v = dL[(size_t)a.k_begin * S + tid];
+        // (agent scope: read back from the L2 the stores above went through to - never a line this CU cached earlier, e.g. when
+        //  lambda0 of a true warm start was loaded from the same array)
+        const T v = __hip_atomic_load(dL + (size_t)a.k_begin * S + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         XGr::store((gu64 *)a.xpeer[a.rank - 1] + a.lam_off + tid * GPV, a.lam_tag, v);
     }
     if (wg == W - 1 && a.rank < a.nranks - 1 && tid < 64 && !aborted) {

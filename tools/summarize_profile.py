@@ -81,7 +81,7 @@ WL = {"iiwa_14_7_k50_f64": ("pcg_single_f64m_kernel<14", 50), "iiwa_14_7_k50_f32
       "iiwa_14_7_k4096_f64": ("pcg_resident_kernel<double, 14", 4096), "s32_c16_k1024_f32": ("pcg_resident_kernel<float, 32", 1024),
       "iiwa_14_7_k131072_f32": ("pcg_dma_kernel<float, 14", 131072), "iiwa_14_7_k131072_f32_semi": ("pcg_resident_kernel<float, 14", 131072),
       "s32_c16_k32768_f32": ("pcg_dma_kernel<float, 32", 32768), "s32_c16_k32768_f32_semi": ("pcg_resident_kernel<float, 32", 32768),
-      "iiwa_14_7_k65536_f64_ring": ("pcg_dma_kernel<double, 14", 65536), "iiwa_14_7_k65536_f64_semi": ("pcg_resident_kernel<double, 14", 65536)}
+      "iiwa_14_7_k65536_f64": ("pcg_dma_kernel<double, 14", 65536), "iiwa_14_7_k65536_f64_semi": ("pcg_resident_kernel<double, 14", 65536)}
 bench = one(f"prof_{tag}_bench.json")
 geom = {}
 if bench:
