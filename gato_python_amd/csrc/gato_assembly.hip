@@ -559,8 +559,7 @@ __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStr
     };
     stamp();
 
-    // (knots [k_lo, k_hi): the whole system, or what one rank of a sharded solve needs - every workgroup is independent of the others)
-    for (int k = bs.k_lo + blockIdx.x; k < bs.k_hi; k += gridDim.x) {
+    for (int k = blockIdx.x; k < K; k += gridDim.x) {
         const bool first = k == 0, last = k == K - 1;
         const bool full0 = k >= 2;                                           // theta_{k-1} is a Schur block (k-1 >= 1)
         const size_t gk = (size_t)k * (SS + CC);
@@ -859,8 +858,7 @@ int launch_assemble(const Dims &d, const AsmArgs &a, hipStream_t st)
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
-    const int nk = d.hi() - d.lo();
-    const int gx = nk < (1 << 20) ? nk : (1 << 20);
+    const int gx = d.K < (1 << 20) ? d.K : (1 << 20);
     hipLaunchKernelGGL((assemble_kernel<T, S, C, NT>), dim3(gx, d.B), dim3(NT), L::BYTES, st, a, d.K, batch_stride(d));
     GATO_HIP_CHECK(hipGetLastError());
     return GATO_OK;

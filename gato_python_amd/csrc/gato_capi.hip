@@ -1758,6 +1758,11 @@ extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_P
         if (ok && total <= 256) { a.flat = 1; a.flat_groups = total; a.flat_base = base; a.flat_off = s->cl.flat_off; }
     }
     s->cl.last_flat = a.flat;
+    // (One-XCD placement of a rank's <= 32 workgroups, as one-GPU launches get, was measured for cluster launches in round 5 and
+    //  not kept: a cluster of one rank at 14/7/512 f32 3.47 -> 3.35 us per iteration, fp64 5.2 -> 5.8; with 8 / 4 ranks sharing a chip
+    //  the flat exchange (5.74 / 4.88) beats two levels with packed level 1 (6.67 / 5.43).  What separates these launches from the
+    //  2.2 us of the plain launch at the same knot count is the lean hand-off with workgroup-scope stores, which the MR kernels'
+    //  level 1 does not have - DESIGN_LOG.md R5.7.)
     a.ev_start = s->time_pcg ? s->ev_pcg0 : nullptr;
     a.ev_stop = s->time_pcg ? s->ev_pcg1 : nullptr;
     s->last_groups = groups; s->last_threads = threads; s->last_mode = GATO_PCG_RESIDENT; s->last_variant = cg1 ? 1 : 0;
@@ -1791,26 +1796,8 @@ extern "C" int gato_cluster_linsys(gato_solver *s, const int *d_G_row, const int
     int rc;
     const bool ts = s->time_stages != 0;
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[0], st));
-    // small shards (what K = 4096 over 8 GPUs gives): ONE fused launch, a workgroup per knot, as the one-GPU whole solve takes for
-    // small systems (asm_mode: 0 = auto by the same rule, 1 = stage kernels, 2 = fused).  The workgroup of knot k writes S[k].left /
-    // .main, S[k-1].right, Pinv[k].main / .left, Pinv[k-1].right, gamma_k, the inverses of knot k and [A | B] of knot k-1: rows
-    // k0-h .. k1-1+h of S / Pinv complete, gamma on k0-1-h .. k1+h and everything dz reads on [k0, k1) come from the workgroups of
-    // the knots [k0-1-h, k1+1+h).  Bit-identical to the stage kernels (test_fused_assembly_is_bit_identical_to_the_stage_kernels).
-    const int span = clip(k1 + 1 + h) - clip(k0 - 1 - h);
-    const bool fused = s->asm_mode == 2 || (s->asm_mode == 0 && span <= 2 * s->num_cus);
-    s->last_asm_fused = fused;
-    if (fused) {
-        AsmArgs aa;
-        memset(&aa, 0, sizeof(aa));
-        aa.mode = 0;
-        aa.G_row = d_G_row; aa.G_col = d_G_col; aa.G_val = d_G_val; aa.C_row = d_C_row; aa.C_col = d_C_col; aa.C_val = d_C_val;
-        aa.rho = rho; aa.g = d_g; aa.c = d_c;
-        aa.Gd = s->G_dense; aa.Cd = s->C_dense; aa.Ginv = s->Ginv; aa.Sbd = s->Sbd; aa.Pbd = s->Pbd; aa.gamma = s->gamma;
-        range(k0 - 1 - h, k1 + 1 + h);
-        rc = s->ops->assemble(s->d, aa, st);
-        s->d.k_lo = s->d.k_hi = 0;
-        if (rc) return rc;
-    } else {
+    // (the fused one-launch assembly of small one-GPU solves was tried here for small shards - 512 knots, what K = 4096 over 8 GPUs
+    //  gives - and measured no better: 31 against 28 us outside the loop, tools/cluster_step_time.py; the stage kernels stay)
     range(k0 - 2 - h, k1 + 1 + h);
     rc = s->ops->convert(s->d, d_G_row, d_G_col, d_G_val, d_C_row, d_C_col, d_C_val, rho, s->G_dense, s->C_dense, nullptr, st);
     // (form_schur inverts the Q_k, R_k of its knot range first and then runs the Schur steps on the same range: the step of the
@@ -1819,7 +1806,6 @@ extern "C" int gato_cluster_linsys(gato_solver *s, const int *d_G_row, const int
     if (!rc) { range(k0 - h, k1 + h); rc = s->ops->form_ss(s->d, s->Sbd, s->Pbd, st); }
     s->d.k_lo = s->d.k_hi = 0;
     if (rc) return rc;
-    }
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[1], st));
     if ((rc = gato_cluster_pcg(s, s->Sbd, s->Pbd, s->gamma, d_lambda, exit_tol, max_iters, d_iters, stream))) return rc;
     if (ts) GATO_HIP_CHECK(hipEventRecord(s->ev_stage[2], st));

@@ -30,6 +30,9 @@ def main():
     for s_ in sols:
         s_.set_option("timeout_ms", 300)
         s_.set_option("cluster_flat", int(os.environ.get("PROBE_FLAT", "1")))
+        s_.set_option("pcg_variant", int(os.environ.get("PROBE_VARIANT", "0")))     # 1: single reduction, one exchange per iteration
+        if R > 4:
+            s_.set_option("max_workgroups", 256 // R)
     cl = [ClusterPCG(s_, r, R, inprocess_peers=True) for r, s_ in enumerate(sols)]
     ClusterPCG.connect_inprocess(cl)
     skip = int(os.environ.get("PROBE_SKIP_STREAMS", "0"))
@@ -48,7 +51,8 @@ def main():
         el = time.perf_counter() - t0
         err = float((lam - lam1).abs().max() / lam1.abs().max())
         print(f"rep {rep}: {el * 1e3:.2f} ms ({el / mi * 1e6:.2f} us/iter) iters {[int(i.cpu()[0]) for i in its]} err vs one GPU {err:.2e} "
-              f"geometry {[(s_.get_option('last_groups'), s_.get_option('last_threads')) for s_ in sols]} flat {sols[0].get_option('last_cluster_flat')}")
+              f"geometry {[(s_.get_option('last_groups'), s_.get_option('last_threads')) for s_ in sols]} flat {sols[0].get_option('last_cluster_flat')} "
+              f"variant {sols[0].get_option('last_variant')}")
     # device time of one launch per rank
     for s_ in sols:
         s_.set_option("time_pcg", 1)
