@@ -472,6 +472,14 @@ __global__ __launch_bounds__(NT, (GatherWaves<T, S>::v)) void gather_kernel(cons
     static_assert(NT % WAVE == 0, "whole waves");
     __shared__ T blk[SS + CC + ABS];                                          // Q_k | R_k | A_k | B_k
     __shared__ int sPtrG[n + 1], sPtrC[S + 1];
+    // COLLISIONS: a CSR row may hold the same column twice (or two columns that fold onto one slot, col % n).  The reference walks a
+    // row with ONE thread, so the LAST entry in storage order wins (gato_schur.cuh:689-702, :733-741); a thread per entry needs a
+    // rule.  Fast path: every entry also sets its slot's bit (one LDS atomic), and only a workgroup that sees a bit set twice
+    // resolves owners: atomicMax of the entry index per slot, then the winners store again.  Valid inputs never take that path.
+    constexpr int NSLOT = SS + CC + ABS;
+    __shared__ unsigned smask[(NSLOT + 31) / 32];
+    __shared__ int sown[NSLOT];
+    __shared__ int s_coll;
     T *sQ = blk, *sR = blk + SS, *sAB = blk + SS + CC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     G_val += blockIdx.y * bs.nnzG; C_val += blockIdx.y * bs.nnzC;            // batch: shared structure, own values
@@ -485,9 +493,24 @@ __global__ __launch_bounds__(NT, (GatherWaves<T, S>::v)) void gather_kernel(cons
         for (int i = tid; i <= nrG; i += NT) sPtrG[i] = G_row[r0 + i];
         if (nrC) for (int i = tid; i <= nrC; i += NT) sPtrC[i] = C_row[c0 + i];
         for (int i = tid; i < SS + CC + ABS; i += NT) blk[i] = (T)0;
+        for (int i = tid; i < (NSLOT + 31) / 32; i += NT) smask[i] = 0u;
+        if (tid == 0) s_coll = 0;
         __syncthreads();
         const int eG0 = sPtrG[0], nG = sPtrG[nrG] - eG0;
         const int eC0 = nrC ? sPtrC[0] : 0, nC = nrC ? sPtrC[nrC] - eC0 : 0;
+        // destination slot in blk of entry t (given its column and value), -1 if the entry is dropped; v = the value stored
+        auto slot_of = [&](int t, int colv, T valv, T &v) -> int {
+            if (t < nG) {                                                  // csr_to_custom_G, gato_schur.cuh:674-704
+                const int isr = row_of_entry(sPtrG, nrG, eG0 + t);
+                const int isc = colv % n;
+                v = valv + (colv == r0 + isr ? rho : (T)0);
+                if (isc < S) return isr < S ? isc * S + isr : -1;
+                return isr >= S ? SS + (isc - S) * C + (isr - S) : -1;
+            }
+            const int i = row_of_entry(sPtrC, nrC, eC0 + (t - nG));        // csr_to_custom_C, :707-743
+            v = valv;
+            return colv / n <= k ? SS + CC + (colv % n) * S + i : -1;
+        };
         constexpr int U = 4;
         for (int t0 = tid; t0 < nG + nC; t0 += NT * U) {
             int col[U];
@@ -501,16 +524,33 @@ __global__ __launch_bounds__(NT, (GatherWaves<T, S>::v)) void gather_kernel(cons
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int t = t0 + u * NT;
-                if (t < nG) {                                              // csr_to_custom_G, gato_schur.cuh:674-704
-                    const int isr = row_of_entry(sPtrG, nrG, eG0 + t);
-                    const int isc = col[u] % n;
-                    const T v = val[u] + (col[u] == r0 + isr ? rho : (T)0);
-                    if (isc < S) { if (isr < S) sQ[isc * S + isr] = v; }
-                    else if (isr >= S) sR[(isc - S) * C + (isr - S)] = v;
-                } else if (t < nG + nC) {                                  // csr_to_custom_C, :707-743
-                    const int i = row_of_entry(sPtrC, nrC, eC0 + (t - nG));
-                    if (col[u] / n <= k) sAB[(col[u] % n) * S + i] = val[u];
+                if (t < nG + nC) {
+                    T v;
+                    const int sl = slot_of(t, col[u], val[u], v);
+                    if (sl >= 0) {
+                        blk[sl] = v;
+                        const unsigned bit = 1u << (sl & 31);
+                        if (atomicOr(&smask[sl >> 5], bit) & bit) s_coll = 1;
+                    }
                 }
+            }
+        }
+        __syncthreads();
+        if (s_coll) {                                                      // workgroup-uniform; never taken for duplicate-free rows
+            for (int i = tid; i < NSLOT; i += NT) sown[i] = -1;
+            __syncthreads();
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int t = tid; t < nG + nC; t += NT) {
+                    const int colv = t < nG ? G_col[eG0 + t] : C_col[eC0 + (t - nG)];
+                    const T valv = t < nG ? G_val[eG0 + t] : C_val[eC0 + (t - nG)];
+                    T v;
+                    const int sl = slot_of(t, colv, valv, v);
+                    if (sl < 0) continue;
+                    // (within a row storage order = index order; entries of different rows never share a slot)
+                    if (pass == 0) atomicMax(&sown[sl], t);
+                    else if (sown[sl] == t) blk[sl] = v;
+                }
+                __syncthreads();
             }
         }
         __syncthreads();
@@ -536,6 +576,11 @@ __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStr
     T *sQ = lds + L::Q, *sR = lds + L::R, *sAB = lds + L::AB, *sPhi = lds + L::PHI, *sBR = lds + L::BR;
     T *sTh = lds + L::TH, *sT = lds + L::TT, *sq = lds + L::VQ, *sv = lds + L::VV;
     int *sPtrG = (int *)(lds + L::ELEMS), *sPtrC = sPtrG + L::PTR_G;
+    // collisions of the CSR scatter (see gather_kernel): slot bits, owners, flag
+    constexpr int NSLOT = 3 * SS + 3 * CC + 2 * ABS;
+    __shared__ unsigned smask[(NSLOT + 31) / 32];
+    __shared__ int sown[NSLOT];
+    __shared__ int s_coll;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sys = blockIdx.y;
     const T *g = (const T *)a.g + sys * bs.n, *c = (const T *)a.c + sys * bs.sk;
@@ -574,9 +619,26 @@ __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStr
             for (int i = tid; i <= nrG; i += NT) sPtrG[i] = a.G_row[r0 + i];
             if (nrC) for (int i = tid; i <= nrC; i += NT) sPtrC[i] = a.C_row[c0 + i];
             for (int i = tid; i < 3 * SS + 3 * CC + 2 * ABS; i += NT) lds[i] = (T)0;   // sQ, sR, sAB are contiguous
+            for (int i = tid; i < (NSLOT + 31) / 32; i += NT) smask[i] = 0u;
+            if (tid == 0) s_coll = 0;
             __syncthreads();
             const int eG0 = sPtrG[0], nG = sPtrG[nrG] - eG0;
             const int eC0 = nrC ? sPtrC[0] : 0, nC = nrC ? sPtrC[nrC] - eC0 : 0;
+            // destination slot of entry t in lds[0 .. NSLOT) (sQ | sR | sAB), -1 if the entry is dropped; v = the value stored
+            auto slot_of = [&](int t, int colv, T valv, T &v) -> int {
+                if (t < nG) {                                              // csr_to_custom_G, gato_schur.cuh:674-704
+                    const int row = r0 + row_of_entry(sPtrG, nrG, eG0 + t);
+                    const int knot = row / n, isr = row - knot * n, qi = knot - (k - 2);
+                    const int isc = colv % n;
+                    v = valv + (colv == row ? rho : (T)0);
+                    if (isc < S) return isr < S ? L::Q + qi * SS + isc * S + isr : -1;
+                    return isr >= S ? L::R + qi * CC + (isc - S) * C + (isr - S) : -1;
+                }
+                const int row = c0 + row_of_entry(sPtrC, nrC, eC0 + (t - nG));   // csr_to_custom_C, :707-743
+                const int br = row / S - 1, i = row - (br + 1) * S;
+                v = valv;
+                return colv / n <= br ? L::AB + (br - (k - 2)) * ABS + (colv % n) * S + i : -1;
+            };
             // U entries per thread and round: all 2U loads are in flight before the first bisection result is needed
             constexpr int U = 4;
             for (int t0 = tid; t0 < nG + nC; t0 += NT * U) {
@@ -591,18 +653,32 @@ __global__ __launch_bounds__(NT) void assemble_kernel(AsmArgs a, int K, BatchStr
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int t = t0 + u * NT;
-                    if (t < nG) {                                          // csr_to_custom_G, gato_schur.cuh:674-704
-                        const int row = r0 + row_of_entry(sPtrG, nrG, eG0 + t);
-                        const int knot = row / n, isr = row - knot * n, qi = knot - (k - 2);
-                        const int isc = col[u] % n;
-                        const T v = val[u] + (col[u] == row ? rho : (T)0);
-                        if (isc < S) { if (isr < S) sQ[qi * SS + isc * S + isr] = v; }
-                        else if (isr >= S) sR[qi * CC + (isc - S) * C + (isr - S)] = v;
-                    } else if (t < nG + nC) {                              // csr_to_custom_C, :707-743
-                        const int row = c0 + row_of_entry(sPtrC, nrC, eC0 + (t - nG));
-                        const int br = row / S - 1, i = row - (br + 1) * S;
-                        if (col[u] / n <= br) sAB[(br - (k - 2)) * ABS + (col[u] % n) * S + i] = val[u];
+                    if (t < nG + nC) {
+                        T v;
+                        const int sl = slot_of(t, col[u], val[u], v);
+                        if (sl >= 0) {
+                            lds[sl] = v;
+                            const unsigned bit = 1u << (sl & 31);
+                            if (atomicOr(&smask[sl >> 5], bit) & bit) s_coll = 1;
+                        }
                     }
+                }
+            }
+            __syncthreads();
+            if (s_coll) {                                                  // a row holds a column twice: the last entry in storage order wins
+                for (int i = tid; i < NSLOT; i += NT) sown[i] = -1;
+                __syncthreads();
+                for (int pass = 0; pass < 2; ++pass) {
+                    for (int t = tid; t < nG + nC; t += NT) {
+                        const int colv = t < nG ? a.G_col[eG0 + t] : a.C_col[eC0 + (t - nG)];
+                        const T valv = t < nG ? G_val[eG0 + t] : C_val[eC0 + (t - nG)];
+                        T v;
+                        const int sl = slot_of(t, colv, valv, v);
+                        if (sl < 0) continue;
+                        if (pass == 0) atomicMax(&sown[sl], t);
+                        else if (sown[sl] == t) lds[sl] = v;
+                    }
+                    __syncthreads();
                 }
             }
         } else {

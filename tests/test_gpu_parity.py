@@ -1143,6 +1143,56 @@ def test_csr_with_unsorted_columns_and_explicit_zeros(dt):
     sol.close()
 
 
+@pytest.mark.parametrize("S,C,K", [(14, 7, 12), (2, 1, 9), (32, 16, 5)])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_csr_rows_with_duplicate_columns_keep_the_last_entry(S, C, K, dt):
+    """COLLISIONS: a CSR row that holds the same column twice (legal CSR; scipy only removes such entries on sum_duplicates()).
+    The reference walks a row with one thread, so the LAST entry in storage order wins - its value, and its own rho if it is
+    the diagonal (gato_schur.cuh:689-702, :733-741).  The scatter here is a thread per entry: it must give the same blocks bit
+    for bit - duplicates next to each other and far apart, in shuffled rows, in G (diagonal and off-diagonal) and in C, through
+    the per-knot gather kernel, the stage path of a whole solve and the fused assembly launch; a batch shares the pattern."""
+    s = synth.make_system(S, C, K, seed=41, dense_q=True)
+    rng = np.random.default_rng(9)
+
+    def with_duplicates(indptr, indices, data, frac):
+        idx, dat, ptr = [], [], [0]
+        for r in range(len(indptr) - 1):
+            cols = list(indices[indptr[r]:indptr[r + 1]]); vals = list(data[indptr[r]:indptr[r + 1]])
+            if cols and rng.random() < frac:
+                for _ in range(int(rng.integers(1, 4))):           # 1..3 extra entries: copies of columns already in the row ...
+                    j = int(rng.integers(0, len(cols)))
+                    at = int(rng.integers(0, len(cols) + 1))       # ... anywhere in the row: before or after the original, adjacent or not
+                    cols.insert(at, cols[j]); vals.insert(at, float(rng.standard_normal()))
+            idx += cols; dat += vals
+            ptr.append(len(idx))
+        return np.asarray(ptr, np.int32), np.asarray(idx, np.int32), np.asarray(dat, np.float64)
+
+    G_row, G_col, G_val = with_duplicates(s.G_row, s.G_col, s.G_val, 0.3)
+    C_row, C_col, C_val = with_duplicates(s.C_row, s.C_col, s.C_val, 0.3)
+    assert len(G_val) > len(s.G_val) and len(C_val) > len(s.C_val)
+    s2 = synth.KKTSystem(S, C, K, G_row, G_col, G_val, C_row, C_col, C_val, s.g, s.c, s.rho)
+    Gd_o, Cd_o = co.convert(*s2.csr_args()[:6], S, C, K, s2.rho, dt)
+    Gd_n, Cd_n = o.convert(*s2.csr_args()[:6], S, C, K, s2.rho, dt)              # both restatements walk a row in order
+    assert np.array_equal(Gd_o, Gd_n) and np.array_equal(Cd_o, Cd_n)
+    sol = make_solver(S, C, K, dt)
+    dev = sol.upload_system(s2)
+    for rep in range(3):                                           # the same answer every time: no race decides the winner
+        Gd, Cd = sol.convert(*dev[:6], s2.rho)
+        assert np.array_equal(host(Gd), Gd_o) and np.array_equal(host(Cd), Cd_o), rep
+    for mode in (1, 2):
+        sol.set_option("asm_mode", mode)
+        for rep in range(2):
+            sol.linsys(*dev, 1e-8, 5, s2.rho)
+            assert np.array_equal(sol.read_buffer("G_dense"), Gd_o) and np.array_equal(sol.read_buffer("C_dense"), Cd_o), (mode, rep)
+    sol.close()
+    # a duplicate-free system afterwards on a fresh solver: the fast path (no owner resolution) still gives the oracle's blocks
+    Gd_c, Cd_c = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
+    sol = make_solver(S, C, K, dt)
+    Gd, Cd = sol.convert(*sol.upload_system(s)[:6], s.rho)
+    assert np.array_equal(host(Gd), Gd_c) and np.array_equal(host(Cd), Cd_c)
+    sol.close()
+
+
 def test_thirteen_workgroups_of_64_threads_1000_launches():
     """The geometry of the one hand-off time-out ever seen on the GPU box (round 1, an uncommitted layout that packed the
     granules of several workgroups into one 128-B line): 13 workgroups x 64 threads at 14/7/50 f32.  The committed
