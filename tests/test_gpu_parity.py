@@ -1143,6 +1143,62 @@ def test_csr_with_unsorted_columns_and_explicit_zeros(dt):
     sol.close()
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_csr_with_structurally_empty_rows(dt):
+    """RAGGED / EMPTY rows: rows of C with no dynamics entries at all (only the identity on x_{k+1} stays, or nothing), rows of G
+    reduced to their diagonal, whole knots whose B block is structurally empty - row pointers repeat, entry counts per knot
+    differ.  Dense blocks bit for bit (gather kernel, stage path, fused launch) and the whole solve against the oracle."""
+    S, C, K = 14, 7, 11
+    s = synth.make_system(S, C, K, seed=43, dense_q=True)
+    rng = np.random.default_rng(11)
+    n = S + C
+
+    def thin(indptr, indices, data, keep):
+        idx, dat, ptr = [], [], [0]
+        for r in range(len(indptr) - 1):
+            for e in range(indptr[r], indptr[r + 1]):
+                if keep(r, int(indices[e])):
+                    idx.append(indices[e]); dat.append(data[e])
+            ptr.append(len(idx))
+        return np.asarray(ptr, np.int32), np.asarray(idx, np.int32), np.asarray(dat, np.float64)
+
+    diag_only = set(int(r) for r in rng.choice(n * K - C, 40, replace=False))
+    G_row, G_col, G_val = thin(s.G_row, s.G_col, s.G_val, lambda r, c: r == c or (r not in diag_only and c not in diag_only))   # (symmetric)
+    bare = set(int(r) for r in rng.choice(np.arange(S, S * K), 25, replace=False))        # C rows that keep only their identity entry
+    gone = set(int(r) for r in rng.choice(np.arange(S, S * K), 6, replace=False))          # ... and rows with NO entry at all
+    noB = {3, 7}                                                                            # knots whose B block is structurally empty
+
+    def keep_c(r, c):
+        if r in gone:
+            return False
+        br = r // S - 1
+        ident = c == (br + 1) * n + r % S
+        if r in bare:
+            return ident
+        if r >= S and br in noB and br * n + S <= c < (br + 1) * n:
+            return False
+        return True
+    C_row, C_col, C_val = thin(s.C_row, s.C_col, s.C_val, keep_c)
+    assert np.any(np.diff(C_row) == 0) and np.any(np.diff(C_row) == 1) and len(C_val) < len(s.C_val)
+    s2 = synth.KKTSystem(S, C, K, G_row, G_col, G_val, C_row, C_col, C_val, s.g, s.c, s.rho)
+    Gd_o, Cd_o = co.convert(*s2.csr_args()[:6], S, C, K, s2.rho, dt)
+    sol = make_solver(S, C, K, dt)
+    dev = sol.upload_system(s2)
+    Gd, Cd = sol.convert(*dev[:6], s2.rho)
+    assert np.array_equal(host(Gd), Gd_o) and np.array_equal(host(Cd), Cd_o)
+    f64 = dt == np.float64
+    tol = 1e-10 if f64 else 1e-5
+    for mode in (1, 2):
+        sol.set_option("asm_mode", mode)
+        lam, dz = sol.new(S * K), sol.new(sol.N)
+        sol.linsys(*dev, tol, 200, s2.rho, lam, dz)
+        sol.check_status()
+        assert np.array_equal(sol.read_buffer("G_dense"), Gd_o) and np.array_equal(sol.read_buffer("C_dense"), Cd_o)
+        check_solve(f"structurally empty rows 14/7/{K} asm_mode {mode}", s2, S, C, K, dt, tol, 200, host(lam), host(dz),
+                    int(np.frombuffer(_read_iters(sol), np.int32)[0]), f64_tol=1e-9)
+    sol.close()
+
+
 @pytest.mark.parametrize("S,C,K", [(14, 7, 12), (2, 1, 9), (32, 16, 5)])
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_csr_rows_with_duplicate_columns_keep_the_last_entry(S, C, K, dt):
