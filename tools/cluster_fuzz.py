@@ -1,0 +1,104 @@
+"""Randomised geometries of the cluster launches on one GPU (R ranks as streams of one process): K, ranks, recurrence, exchange form,
+type, workgroup size - every PCG solve against the C oracle (default recurrence) or the numpy restatement of the single-reduction
+recurrence, every whole sharded solve (gato_cluster_linsys) against the oracle's whole solve.  Prints the failing case, if any.
+      python tools/cluster_fuzz.py [cases] [seed]"""
+import os, sys
+import numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gato_python_amd import synth
+from gato_python_amd.dist import ClusterPCG, lockstep_streams
+from gato_python_amd.solver import Solver
+from oracle import c_oracle as co
+from oracle import gato_oracle as o
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def case(rng, i):
+    S, C = [(14, 7), (14, 7), (2, 1), (12, 6), (32, 16), (4, 2), (6, 3)][int(rng.integers(0, 7))]
+    R = int(rng.integers(2, 9))
+    kmax = {2: 3000, 4: 1500, 6: 1000, 12: 700, 14: 900, 32: 260}[S]
+    K = int(rng.integers(2 * R, kmax))
+    variant, flat = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    threads = int(rng.choice([0, 0, 64, 128, 256, 512]))
+    dt = np.float64                        # fp64: equal iteration counts, tight tolerances (fp32 runs the same code paths)
+    tag = f"case {i}: {S}/{C}/{K} R={R} variant={variant} flat={flat} threads={threads}"
+    s = synth.make_system(S, C, K, seed=1000 + i)
+    Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
+    Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+    Pb = co.form_ss(Sb, Pb, S, K)
+    tol, mi = 1e-9, 200
+    lam_o, it_o = co.pcg(Sb, Pb, gam, S, K, tol, mi)
+    sols = [Solver(S, C, K, dt) for _ in range(R)]
+    for x in sols:
+        x.set_option("pcg_variant", variant); x.set_option("cluster_flat", flat); x.set_option("pcg_threads", threads)
+        x.set_option("max_workgroups", max(1, 256 // R)); x.set_option("timeout_ms", 500)
+    cl = [ClusterPCG(x, r, R, inprocess_peers=True) for r, x in enumerate(sols)]
+    ClusterPCG.connect_inprocess(cl)
+    streams = lockstep_streams(R)
+    dS, dP, dg = sols[0].to_device(Sb), sols[0].to_device(Pb), sols[0].to_device(gam)
+    lam = torch.zeros(S * K, dtype=torch.float64, device="cuda")
+    its = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(R)]
+    torch.cuda.synchronize()
+    try:
+        for r in range(R):
+            cl[r].pcg(dS, dP, dg, tol, mi, lam, its[r], stream=streams[r].cuda_stream)
+    except Exception as e:          # a geometry the options do not allow (every rank alike): not a failure
+        torch.cuda.synchronize()
+        for c in cl: c.close()
+        for x in sols: x.close()
+        return tag + f" skipped ({str(e)[:60]})", True
+    torch.cuda.synchronize()
+    got_it = [int(t.cpu()[0]) for t in its]
+    ran = sols[0].get_option("last_variant")
+    ok = len(set(got_it)) == 1
+    for x in sols:
+        try:
+            x.check_status()
+        except Exception:
+            ok = False
+    if ran:
+        lam_c, it_c = o.pcg_single_reduction(Sb, Pb, gam, S, K, tol, mi)
+        ok = ok and got_it[0] == it_c and rel(lam.cpu().numpy(), lam_c) < 1e-7 and rel(lam.cpu().numpy(), lam_o) < 1e-5
+    else:
+        ok = ok and got_it[0] == it_o and rel(lam.cpu().numpy(), lam_o) < 1e-8
+    msg = f"{tag} ran_variant={ran} groups={[x.get_option('last_groups') for x in sols]} iters={got_it} (oracle {it_o}) rel {rel(lam.cpu().numpy(), lam_o):.1e}"
+    # whole sharded solve through the one-call entry
+    d = sols[0].upload_system(s)
+    lams = [torch.full((S * K,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(R)]
+    dzs = [torch.full((sols[0].N,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(R)]
+    torch.cuda.synchronize()
+    for r in range(R):
+        cl[r].linsys(d, tol, mi, s.rho, lams[r], dzs[r], its[r], stream=streams[r].cuda_stream)
+    torch.cuda.synchronize()
+    lam_w, dz_w, it_w = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
+    n = S + C
+    lam_a, dz_a = np.empty(S * K), np.empty(sols[0].N)
+    for r in range(R):
+        k0, k1 = cl[r].k0, cl[r].k1
+        lam_a[k0 * S:k1 * S] = lams[r][k0 * S:k1 * S].cpu().numpy()
+        hi = min(k1 * n, sols[0].N)
+        dz_a[k0 * n:hi] = dzs[r][k0 * n:hi].cpu().numpy()
+    bar = 1e-5 if ran else 1e-8
+    ok2 = rel(lam_a, lam_w) < bar and rel(dz_a, dz_w) < bar and np.isfinite(lam_a).all() and np.isfinite(dz_a).all()
+    msg += f" | whole solve rel lam {rel(lam_a, lam_w):.1e} dz {rel(dz_a, dz_w):.1e}"
+    for c in cl: c.close()
+    for x in sols: x.close()
+    return msg, ok and ok2
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = 0
+    for i in range(n):
+        msg, ok = case(rng, i)
+        print(("ok   " if ok else "FAIL ") + msg, flush=True)
+        bad += 0 if ok else 1
+    print("FUZZ", "FAILED" if bad else "ok", bad)
+    sys.exit(1 if bad else 0)
