@@ -176,6 +176,7 @@ struct gato_solver {
         unsigned xepoch;
         int last_flat;
         int mem_kind;                 // 0 uncached, 1 fine-grained, 2 plain hipMalloc
+        size_t alloc_bytes;           // size of the allocation behind local (>= bytes: recycled mirrors, mirror_take)
     } cl;
     struct { const void *Ginv, *Cd, *g; void *dz; } fz;   // set by the whole-solve entries: dz may ride in the PCG launch
     void *imgS, *imgP;                // column-major images of S and Pinv over all rows (one system; nullptr: none), see PcgLaunch::imgS
@@ -1537,12 +1538,45 @@ extern "C" int gato_shard_pcg_finish(gato_solver *s, const void *d_recvB_last, v
 // One process per GPU.  Every rank owns a MIRROR - a few KB of fine-grained device memory, IPC-shared - into which the
 // peers store {epoch, payload} granules with system-scope stores over xGMI; a rank only ever polls its own mirror.  See
 // pcg_resident_kernel<..., MR = true> for the protocol.  RCCL (gato_shard_pcg_*) stays as the portable fallback.
+// Mirrors are RECYCLED inside the process, never handed back to the allocator while it lives: pages that were mapped uncached
+// and come back as ordinary (cached) device memory after hipFree can read stale - round 5, tools/cluster_fuzz.py: a solver arena
+// allocated over a freed uncached mirror read whole 128-B lines of zeros where the mirror's polled lines had been (P / gamma rows
+// of a later solve; only with the uncached kind, not with fine-grained or plain mirrors).  A few hundred KB per mirror.
+namespace {
+struct MirrorBuf { void *p; size_t bytes; int device, kind; };
+std::mutex g_mirror_mu;
+std::vector<MirrorBuf> g_mirror_pool;
+
+void *mirror_take(int device, int kind, size_t bytes, size_t *got)
+{
+    std::lock_guard<std::mutex> lock(g_mirror_mu);
+    for (size_t i = 0; i < g_mirror_pool.size(); ++i) {
+        const MirrorBuf b = g_mirror_pool[i];
+        if (b.device == device && b.kind == kind && b.bytes >= bytes && b.bytes <= 4 * bytes) {
+            g_mirror_pool[i] = g_mirror_pool.back();
+            g_mirror_pool.pop_back();
+            *got = b.bytes;
+            return b.p;
+        }
+    }
+    return nullptr;
+}
+
+void mirror_give(void *p, int device, int kind, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_mirror_mu);
+    g_mirror_pool.push_back(MirrorBuf{p, bytes, device, kind});
+}
+}  // namespace
+
 static int cluster_alloc(gato_solver *s)
 {
     const char *env = getenv("GATO_XMEM");           // uncached | finegrained | plain (default: first that works)
     const int first = env ? (!strcmp(env, "plain") ? 2 : !strcmp(env, "finegrained") ? 1 : 0) : 0;
     void *p = nullptr;
+    s->cl.alloc_bytes = s->cl.bytes;
     for (int kind = first; kind < 3; ++kind) {
+        if ((p = mirror_take(s->device, kind, s->cl.bytes, &s->cl.alloc_bytes))) { s->cl.mem_kind = kind; break; }
         hipError_t e = kind == 0 ? hipExtMallocWithFlags(&p, s->cl.bytes, hipDeviceMallocUncached)
                      : kind == 1 ? hipExtMallocWithFlags(&p, s->cl.bytes, hipDeviceMallocFinegrained)
                                  : hipMalloc(&p, s->cl.bytes);
@@ -1634,7 +1668,7 @@ extern "C" int gato_cluster_destroy(gato_solver *s)
     if (!s) return GATO_OK;
     for (int r = 0; r < GATO_MAX_RANKS; ++r)
         if (s->cl.opened[r] && s->cl.peer[r]) (void)hipIpcCloseMemHandle(s->cl.peer[r]);
-    if (s->cl.local) (void)hipFree(s->cl.local);
+    if (s->cl.local) mirror_give(s->cl.local, s->device, s->cl.mem_kind, s->cl.alloc_bytes);      // kept for the next cluster
     memset(&s->cl, 0, sizeof(s->cl));
     return GATO_OK;
 }

@@ -370,3 +370,20 @@ def test_cluster_true_warm_start_and_eta_history(flat):
         assert np.allclose(x.eta_history(n1 + 1), h1, rtol=1e-9, atol=0)
     for x in sols + [one]:
         x.close()
+
+
+def test_clusters_created_and_destroyed_in_one_process():
+    """Randomised cluster geometries one after the other in ONE process (tools/cluster_fuzz.py, fixed seed): solvers and
+    clusters are destroyed and re-created between the cases, so each case runs on memory the previous ones gave back.  Cases
+    27-31 of seed 1 are the sequence that read stale lines in round 5 (an arena allocated over a freed uncached mirror, see
+    mirror_take in gato_capi.hip); every PCG solve and every whole sharded solve is held against the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import cluster_fuzz
+    rng = np.random.default_rng(1)
+    only = set(range(20, 36))
+    bad = []
+    for i in range(36):
+        msg, ok = cluster_fuzz.case(rng, i, only)
+        if not ok:
+            bad.append(msg)
+    assert not bad, "\n".join(bad)

@@ -1,7 +1,10 @@
 """Randomised geometries of the cluster launches on one GPU (R ranks as streams of one process): K, ranks, recurrence, exchange form,
 type, workgroup size - every PCG solve against the C oracle (default recurrence) or the numpy restatement of the single-reduction
 recurrence, every whole sharded solve (gato_cluster_linsys) against the oracle's whole solve.  Prints the failing case, if any.
-      python tools/cluster_fuzz.py [cases] [seed]"""
+Solvers and clusters are created and destroyed case after case in one process, so the run also covers what one cluster leaves
+behind for the next (round 5: recycled uncached mirrors, gato_capi.hip mirror_take; FUZZ_ONLY=29,30,31 with seed 1 was the
+shortest sequence that showed it).
+      python tools/cluster_fuzz.py [cases] [seed]          FUZZ_ONLY=i,j,...: draw every case, run only these"""
 import os, sys
 import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
@@ -19,7 +22,7 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-def case(rng, i):
+def case(rng, i, only=None):
     S, C = [(14, 7), (14, 7), (2, 1), (12, 6), (32, 16), (4, 2), (6, 3)][int(rng.integers(0, 7))]
     R = int(rng.integers(2, 9))
     kmax = {2: 3000, 4: 1500, 6: 1000, 12: 700, 14: 900, 32: 260}[S]
@@ -28,6 +31,8 @@ def case(rng, i):
     threads = int(rng.choice([0, 0, 64, 128, 256, 512]))
     dt = np.float64                        # fp64: equal iteration counts, tight tolerances (fp32 runs the same code paths)
     tag = f"case {i}: {S}/{C}/{K} R={R} variant={variant} flat={flat} threads={threads}"
+    if only is not None and i not in only:
+        return tag + " not run", True
     s = synth.make_system(S, C, K, seed=1000 + i)
     Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
     Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
@@ -76,6 +81,13 @@ def case(rng, i):
     for r in range(R):
         cl[r].linsys(d, tol, mi, s.rho, lams[r], dzs[r], its[r], stream=streams[r].cuda_stream)
     torch.cuda.synchronize()
+    it_whole = [int(t.cpu()[0]) for t in its]
+    st_whole = []
+    for x in sols:
+        try:
+            x.check_status(); st_whole.append("")
+        except Exception as e:
+            st_whole.append(str(e)[:80])
     lam_w, dz_w, it_w = co.linsys_solve(*s.csr_args(), S, C, K, tol, mi, s.rho, dtype=dt)
     n = S + C
     lam_a, dz_a = np.empty(S * K), np.empty(sols[0].N)
@@ -86,7 +98,10 @@ def case(rng, i):
         dz_a[k0 * n:hi] = dzs[r][k0 * n:hi].cpu().numpy()
     bar = 1e-5 if ran else 1e-8
     ok2 = rel(lam_a, lam_w) < bar and rel(dz_a, dz_w) < bar and np.isfinite(lam_a).all() and np.isfinite(dz_a).all()
-    msg += f" | whole solve rel lam {rel(lam_a, lam_w):.1e} dz {rel(dz_a, dz_w):.1e}"
+    ok2 = ok2 and len(set(it_whole)) == 1 and (ran or it_whole[0] == it_w)
+    msg += f" | whole solve rel lam {rel(lam_a, lam_w):.1e} dz {rel(dz_a, dz_w):.1e} iters {it_whole if len(set(it_whole)) > 1 else it_whole[0]} (oracle {it_w})"
+    if any(st_whole):
+        msg += f" status {st_whole}"
     for c in cl: c.close()
     for x in sols: x.close()
     return msg, ok and ok2
@@ -96,8 +111,11 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     bad = 0
+    only = {int(v) for v in os.environ["FUZZ_ONLY"].split(",")} if os.environ.get("FUZZ_ONLY") else None
     for i in range(n):
-        msg, ok = case(rng, i)
+        msg, ok = case(rng, i, only)
+        if msg.endswith("not run"):
+            continue
         print(("ok   " if ok else "FAIL ") + msg, flush=True)
         bad += 0 if ok else 1
     print("FUZZ", "FAILED" if bad else "ok", bad)
