@@ -387,3 +387,18 @@ def test_clusters_created_and_destroyed_in_one_process():
         if not ok:
             bad.append(msg)
     assert not bad, "\n".join(bad)
+
+
+def test_cluster_states_connected_and_closed_across_processes():
+    """THREE PROCESSES, a fixed-seed slice of tools/cluster_fuzz_ipc.py: twenty random geometries one after the other, each with a
+    fresh cluster state (mirrors re-exported and re-mapped through hipIpc handles), two whole solves per state through
+    linsys_solve_cluster / linsys_solve_auto - the second with another system and sometimes the other recurrence - then
+    close_state; every rank holds the gathered lambda / dz against the oracle's whole solve."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), OMP_NUM_THREADS="4",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
+           os.path.join(ROOT, "tools", "cluster_fuzz_ipc.py"), "20", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "FUZZ ok 0" in r.stdout and r.stdout.count("\nok   case") + r.stdout.startswith("ok   case") == 20, r.stdout[-3000:]
