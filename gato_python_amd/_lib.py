@@ -30,7 +30,7 @@ SYMBOLS = [
     "gato_shard_pcg_init", "gato_shard_pcg_phase_a", "gato_shard_pcg_phase_b", "gato_shard_pcg_finish",
     "gato_shard_pcg_done", "gato_linsys_device_blocks", "gato_release_cache", "gato_solver_recover",
     "gato_cluster_knot_range", "gato_cluster_create", "gato_cluster_local_mirror", "gato_cluster_connect",
-    "gato_cluster_pcg", "gato_cluster_linsys", "gato_cluster_destroy", "gato_cluster_fits", "gato_last_stage_ms", "gato_solver_tune",
+    "gato_cluster_pcg", "gato_cluster_linsys", "gato_cluster_destroy", "gato_cluster_launches_left", "gato_cluster_rewind", "gato_cluster_fits", "gato_last_stage_ms", "gato_solver_tune",
 ]
 
 
@@ -97,6 +97,8 @@ def lib() -> ct.CDLL:
         L.gato_cluster_pcg.argtypes = [vp, vp, vp, vp, vp, d, i, vp, vp]
         L.gato_cluster_linsys.argtypes = [vp, ip, ip, vp, ip, ip, vp, vp, vp, d, i, d, vp, vp, vp, vp]
         L.gato_cluster_destroy.argtypes = [vp]
+        L.gato_cluster_launches_left.argtypes = [vp, i, ct.POINTER(ct.c_longlong)]
+        L.gato_cluster_rewind.argtypes = [vp]
         L.gato_cluster_fits.argtypes = [vp, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int)]
         L.gato_solver_tune.argtypes = [vp, vp]
         f = ct.c_float

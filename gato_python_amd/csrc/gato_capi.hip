@@ -324,6 +324,7 @@ extern "C" int gato_infer_shape(const int *C_row, int len_C_row, int len_g, int 
 
 extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype, int device, gato_solver **out);
 extern "C" int gato_cluster_destroy(gato_solver *s);
+extern "C" int gato_cluster_rewind(gato_solver *s);
 extern "C" int gato_compute_dz(gato_solver *s, const void *d_Ginv_dense, const void *d_C_dense, const void *d_g,
                                const void *d_lambda, void *d_dz, void *stream);
 extern "C" int gato_pcg(gato_solver *s, const void *d_S, const void *d_Pinv, const void *d_gamma, void *d_lambda,
@@ -481,6 +482,7 @@ extern "C" int gato_solver_set_option(gato_solver *s, const char *name, int valu
     else if (!strcmp(name, "asm_mode")) s->asm_mode = value;
     else if (!strcmp(name, "pcg_semi")) s->pcg_semi = value;
     else if (!strcmp(name, "pcg_epoch")) s->pcg_epoch = (unsigned)value;      // test hook: place the counter near its wrap
+    else if (!strcmp(name, "cluster_epoch")) s->cl.xepoch = (unsigned)value;  // test hook: the cluster's counter near its end (every rank alike)
     else if (!strcmp(name, "stamp_asm")) s->stamp_asm = value;
     else if (!strcmp(name, "stamp_pcg")) s->stamp_pcg = value;
     else if (!strcmp(name, "ablate")) s->ablate = value;
@@ -1653,13 +1655,36 @@ extern "C" int gato_cluster_connect(gato_solver *s, const void *ipc_handles, voi
         s->cl.opened[r] = true;
     }
     GATO_HIP_CHECK(hipMemcpy(s->cl_tab, s->cl.peer, sizeof(void *) * GATO_MAX_RANKS, hipMemcpyHostToDevice));
-    // fresh epoch spaces on both levels (every rank does the same, then the caller's barrier)
+    s->cl.on = 1;
+    return gato_cluster_rewind(s);                 // fresh epoch spaces on both levels (every rank does the same, then the caller's barrier)
+}
+
+// The hand-off epochs of a cluster only grow (32 bits; a launch takes 2 max_iters + 8 of them on every rank alike), and a mirror
+// cannot be re-zeroed in stream order as the one-GPU slots are: a peer that is already in its next launch may have stored into it.
+// So the epoch space is renewed by the CALLER, on every rank at the same solve: when gato_cluster_launches_left says that the next
+// launch does not fit (the counters run in lock-step, every rank sees it at the same call), each rank waits for its own
+// launches, all ranks pass a host barrier (nobody stores into a mirror any more), each rank calls gato_cluster_rewind (zeroes its
+// mirror and its level-1 slots, counters back to 0), all pass a second barrier, and the solves go on.  dist.ClusterPCG does this.
+extern "C" int gato_cluster_launches_left(gato_solver *s, int max_iters, long long *left)
+{
+    if (!s->cl.on || !left) { set_error("cluster_launches_left: gato_cluster_connect first"); return GATO_EINVAL; }
+    const unsigned long long need = max_iters > 0x3FFFFFF0 ? 0x80000000ull : 2ull * (unsigned)max_iters + 8ull;
+    const unsigned long long top = 0xFFFFFFFFull - need - 8ull;
+    const unsigned long long used = s->cl.xepoch;          // (the level-1 counter of a rank renews itself in stream order: gato_cluster_pcg)
+    *left = used > top ? 0 : (long long)((top - used) / need) + 1;
+    return GATO_OK;
+}
+
+extern "C" int gato_cluster_rewind(gato_solver *s)
+{
+    if (!s->cl.local) { set_error("cluster_rewind: gato_cluster_create first"); return GATO_EINVAL; }
+    GATO_HIP_CHECK(hipSetDevice(s->device));
+    GATO_HIP_CHECK(hipDeviceSynchronize());
     GATO_HIP_CHECK(hipMemset(s->cl.local, 0, s->cl.bytes));
     GATO_HIP_CHECK(hipMemset(s->slots, 0, s->slots_bytes));
     GATO_HIP_CHECK(hipDeviceSynchronize());
     s->pcg_epoch = 0;
     s->cl.xepoch = 0;
-    s->cl.on = 1;
     return GATO_OK;
 }
 
@@ -1742,7 +1767,7 @@ extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_P
     }
     const unsigned need = max_iters > 0x3FFFFFF0 ? 0x80000000u : 2u * (unsigned)max_iters + 8u;
     if (s->cl.xepoch > 0xFFFFFFFFu - need - 8u) {
-        set_error("cluster_pcg: epoch space used up - reconnect the cluster (gato_cluster_connect + barrier)");
+        set_error("cluster_pcg: epoch space used up - renew it on every rank (gato_cluster_launches_left / gato_cluster_rewind between two barriers)");
         return GATO_EINVAL;
     }
     if (s->pcg_epoch > 0xFFFFFFFFu - need - 8u) {

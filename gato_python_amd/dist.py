@@ -246,6 +246,7 @@ class ClusterPCG:
         self.k0, self.k1 = k0.value, k1.value
         self._handle = (ct.c_char * 64)()
         self._inprocess = inprocess_peers is not None
+        self._peers, self.rewinds = None, 0          # ranks of one process (connect_inprocess); epoch-space renewals so far
         if self._inprocess:
             _lib.check(L.gato_cluster_create(solver._h, rank, nranks, None))
         else:
@@ -293,9 +294,39 @@ class ClusterPCG:
         arr = (ct.c_void_p * n)(*[c.mirror for c in clusters])
         for c in clusters:
             c._lib.check(c._lib.lib().gato_cluster_connect(c.sol._h, None, arr))
+            c._peers = list(clusters)
+
+    def launches_left(self, max_iters):
+        """Launches with this max_iters that still fit the cluster's 32-bit epoch space (the same number on every rank)."""
+        left = ct.c_longlong()
+        self._lib.check(self._lib.lib().gato_cluster_launches_left(self.sol._h, int(max_iters), ct.byref(left)))
+        return left.value
+
+    def _renew_epochs_if_used_up(self, max_iters):
+        """The hand-off epochs only grow; after about ten million 200-iteration solves the space is used up - on every rank at the
+        same solve, the counters run in lock-step.  Then: wait for the own launches, barrier (nobody stores into a mirror any
+        more), gato_cluster_rewind (mirror and slots zeroed, counters back to 0), barrier, go on.  Ranks living in one process are
+        rewound together by the first one that notices."""
+        if self.launches_left(max_iters) > 0:
+            return
+        import torch
+        L = self._lib.lib()
+        if self._inprocess:
+            torch.cuda.synchronize()
+            for c in (self._peers or [self]):
+                c._lib.check(L.gato_cluster_rewind(c.sol._h))
+                c.rewinds += 1
+            return
+        import torch.distributed as dist
+        torch.cuda.synchronize(self.sol.device)
+        dist.barrier(group=self.group)
+        self._lib.check(L.gato_cluster_rewind(self.sol._h))
+        dist.barrier(group=self.group)
+        self.rewinds += 1
 
     def pcg(self, Sb, Pb, gamma, exit_tol, max_iters, lam, iters, stream=None):
         """Enqueue this rank's launch.  lam: full-length S*K buffer, this rank's slice is written."""
+        self._renew_epochs_if_used_up(max_iters)
         st = self.sol._stream() if stream is None else ct.c_void_p(stream)
         p = lambda t: ct.c_void_p(t.data_ptr())
         self._lib.check(self._lib.lib().gato_cluster_pcg(self.sol._h, p(Sb), p(Pb), p(gamma), p(lam), float(exit_tol),
@@ -305,6 +336,7 @@ class ClusterPCG:
         """Enqueue this rank's part of a WHOLE solve (gato_cluster_linsys): the stage kernels on the knots its shard reads, its
         persistent launch, dz on its range - one call, nothing on the host or in a collective in between.  d: the device inputs
         of Solver.upload_system (replicated on every rank); lam / dz: full-length buffers, this rank's rows are written."""
+        self._renew_epochs_if_used_up(max_iters)
         st = self.sol._stream() if stream is None else ct.c_void_p(stream)
         p = lambda t: ct.c_void_p(t.data_ptr())
         self._lib.check(self._lib.lib().gato_cluster_linsys(self.sol._h, p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(d[5]), p(d[6]),

@@ -260,6 +260,13 @@ int gato_cluster_linsys(gato_solver *s, const int *d_G_row, const int *d_G_col, 
                         const int *d_C_col, const void *d_C_val, const void *d_g, const void *d_c, double exit_tol,
                         int max_iters, double rho, void *d_lambda, void *d_dz, int *d_iters, void *stream);
 int gato_cluster_destroy(gato_solver *s);
+/* The hand-off epochs of a cluster only grow (32 bits; a launch takes 2 max_iters + 8 on every rank alike: about ten million
+ * 200-iteration solves).  gato_cluster_launches_left: how many launches with this max_iters still fit (the same number on every
+ * rank).  When it reaches 0 the caller renews the epoch space on EVERY rank at the same solve: wait for the rank's own launches,
+ * host barrier over the ranks, gato_cluster_rewind (zeroes the mirror and the level-1 slots, counters back to 0), second barrier.
+ * gato_cluster_pcg / gato_cluster_linsys refuse a launch that does not fit (GATO_EINVAL). */
+int gato_cluster_launches_left(gato_solver *s, int max_iters, long long *left);
+int gato_cluster_rewind(gato_solver *s);
 
 /* ---- direct block input (new): the caller already holds the per-knot blocks in the
  * reference's dense layouts - d_G_blocks as G_dense WITHOUT rho, d_C_blocks as C_dense - so the CSR scatter is

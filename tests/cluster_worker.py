@@ -64,6 +64,24 @@ def main():
             den = np.abs(truth).max()
             eg, eo = np.abs(full.numpy() - truth).max() / den, np.abs(lam_o.astype(np.float64) - truth).max() / den
             assert eg <= 2.0 * eo + 5e-6, (eg, eo)
+    # the cluster's 32-bit epoch space, two launches before its end on every rank (test hook): the third solve renews it - every
+    # rank waits for its launches, barrier, mirrors and slots zeroed, barrier - and the solves go on
+    need = 2 * mi + 8
+    top = 0xFFFFFFFF - need - 8
+    dist.barrier()
+    sol.set_option("cluster_epoch", (top - need - 5) - (1 << 32))
+    sol.set_option("pcg_epoch", (top - need - 5) - (1 << 32))
+    assert cl.launches_left(mi) == 2
+    for rep in range(4):
+        lam = torch.zeros(S * K, dtype=sol.dtype, device="cuda:0")
+        cl.pcg(dS, dP, dg, tol, mi, lam, iters)
+        torch.cuda.synchronize()
+        sol.check_status()
+        assert abs(int(iters.cpu()[0]) - it_o) <= ((0 if f64 else 2) + (1 if variant else 0))
+        mine = lam.cpu().numpy()[cl.k0 * S:cl.k1 * S]
+        assert np.abs(mine - lam_o[cl.k0 * S:cl.k1 * S]).max() / np.abs(lam_o).max() < ((1e-8 if variant else 1e-9) if f64 else 2e-3)
+        assert cl.rewinds == (0 if rep < 2 else 1), (rep, cl.rewinds)
+    assert cl.launches_left(mi) > 1_000_000
     mem = sol.get_option("cluster_mem_kind")
     groups, threads = sol.get_option("last_groups"), sol.get_option("last_threads")
     dist.barrier()

@@ -150,6 +150,61 @@ def test_cluster_back_to_back_solves_and_fixed_iterations():
         s_.close()
 
 
+@pytest.mark.parametrize("variant,flat", [(0, 1), (0, 0), (1, 1), (1, 0)])
+def test_cluster_renews_its_epoch_space(variant, flat):
+    """The hand-off epochs of a cluster only grow; ten million solves use the 32 bits up.  The counters of every rank are placed
+    two launches before the end (test hook cluster_epoch): the third solve renews the space - mirrors and slots zeroed on every
+    rank between two waits - and the solves go on with the same bits; the C entry alone refuses the launch that does not fit."""
+    from gato_python_amd.dist import ClusterPCG
+    from gato_python_amd.solver import Solver
+    S, C, K, R, dt, mi = 14, 7, 300, 3, np.float64, 40
+    Sb, Pb, gam = oracle_blocks(S, C, K, dt)
+    lam_o = (o.pcg_single_reduction(Sb, Pb, gam, S, K, 0.0, mi) if variant else co.pcg(Sb, Pb, gam, S, K, 0.0, mi))[0]
+    sols = [Solver(S, C, K, dt) for _ in range(R)]
+    for x in sols:
+        x.set_option("pcg_variant", variant)
+        x.set_option("cluster_flat", flat)
+    dS, dP, dg = sols[0].to_device(Sb), sols[0].to_device(Pb), sols[0].to_device(gam)
+    cl = [ClusterPCG(s_, r, R, inprocess_peers=True) for r, s_ in enumerate(sols)]
+    ClusterPCG.connect_inprocess(cl)
+    need = 2 * mi + 8
+    top = 0xFFFFFFFF - need - 8
+    for x in sols:
+        x.set_option("cluster_epoch", (top - need - 5) - (1 << 32))     # as a C int: two launches left
+        x.set_option("pcg_epoch", (top - need - 5) - (1 << 32))
+    assert [c.launches_left(mi) for c in cl] == [2] * R
+    streams = lockstep_streams(R)
+    first = None
+    for rep in range(5):
+        lam = torch.zeros(S * K, dtype=torch.float64, device="cuda")
+        its = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(R)]
+        torch.cuda.synchronize()
+        for r in range(R):
+            cl[r].pcg(dS, dP, dg, 0.0, mi, lam, its[r], stream=streams[r].cuda_stream)
+        torch.cuda.synchronize()
+        assert [int(i.cpu()[0]) for i in its] == [mi] * R, rep
+        got = lam.cpu().numpy()
+        assert np.abs(got - lam_o).max() / np.abs(lam_o).max() < (1e-7 if variant else 1e-9), rep
+        first = got if first is None else first
+        assert np.array_equal(got, first), rep
+        assert [c.rewinds for c in cl] == [0 if rep < 2 else 1] * R
+    assert cl[0].launches_left(mi) > 5_000_000
+    # the C entry by itself: a launch that does not fit is refused
+    for x in sols:
+        x.set_option("cluster_epoch", top + 1 - (1 << 32))
+    assert cl[0].launches_left(mi) == 0
+    lam = torch.zeros(S * K, dtype=torch.float64, device="cuda")
+    it = torch.zeros(1, dtype=torch.int32, device="cuda")
+    p = lambda t: __import__("ctypes").c_void_p(t.data_ptr())
+    rc = _lib.lib().gato_cluster_pcg(sols[0]._h, p(dS), p(dP), p(dg), p(lam), 0.0, mi, p(it), None)
+    assert rc != 0 and b"epoch space" in _lib.lib().gato_last_error()
+    for c in cl:
+        c.close()
+    for x in sols:
+        x.check_status()
+        x.close()
+
+
 @pytest.mark.parametrize("S,C,K,semi", [(14, 7, 30000, 1), (14, 7, 30000, 3), (32, 16, 9000, 3)])
 def test_cluster_semi_resident_shards(S, C, K, semi):
     """Shards beyond the register file against the streaming kernels on one GPU: the semi-resident launch per rank (semi = 1)
