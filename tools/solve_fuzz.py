@@ -64,7 +64,15 @@ def draw(rng, i):
     B = int(rng.integers(2, 9)) if entry == "batch" else 1
     if entry == "batch":
         K = min(K, 600)
-    return dict(i=i, S=S, C=C, K=K, dt=dt, entry=entry, opts=opts, tol=tol, mi=mi, rho=rho, dense_q=dense_q, B=B)
+    # extensions beside the reference's behaviour: a true warm start from a random lambda0 (N2), the reference's other two
+    # preconditioner builds (block-Jacobi, point-Jacobi) - device and stage entries, default recurrence
+    extra = int(rng.integers(0, 6))
+    warm = entry in ("device", "stages") and extra == 0
+    precon = int(rng.integers(1, 3)) if entry == "device" and extra == 1 else 0
+    if warm or precon:
+        opts.pop("pcg_variant", None)
+        K = min(K, 6000 if warm else 1500)                # the numpy restatement checks these
+    return dict(i=i, S=S, C=C, K=K, dt=dt, entry=entry, opts=opts, tol=tol, mi=mi, rho=rho, dense_q=dense_q, B=B, warm=warm, precon=precon)
 
 
 def oracle_solve(s, p, variant):
@@ -73,7 +81,15 @@ def oracle_solve(s, p, variant):
     out = []
     for t in ([dt] if dt == np.float64 else [dt, np.float64]):
         a = [np.asarray(x, dt).astype(t) if x.dtype.kind == "f" else x for x in s.csr_args()]
-        if not variant:
+        if p["warm"]:
+            Gd, Cd = co.convert(*a[:6], S, C, K, dt(p["rho"]).astype(t), t)
+            Sb, Pb, gam, Gi = co.form_schur(Gd, Cd, a[6], a[7], S, C, K)
+            Pb = co.form_ss(Sb, Pb, S, K)
+            lam, it = o.pcg(Sb, Pb, gam, S, K, p["tol"], p["mi"], lam0=np.asarray(p["lam0"], dt).astype(t))
+            out.append((lam.reshape(-1), co.compute_dz(Gi, Cd, a[6], lam.reshape(-1), S, C, K), it))
+        elif p["precon"]:
+            out.append(o.linsys_solve(*a, S, C, K, p["tol"], p["mi"], dt(p["rho"]).astype(t), dtype=t, precon_mode=p["precon"])[:3])
+        elif not variant:
             out.append(co.linsys_solve(*a, S, C, K, p["tol"], p["mi"], dt(p["rho"]).astype(t), dtype=t))
         else:
             Gd, Cd = co.convert(*a[:6], S, C, K, dt(p["rho"]).astype(t), t)
@@ -97,11 +113,15 @@ def run_gpu(s, p, systems):
     try:
         for k, v in p["opts"].items():
             sol.set_option(k, v)
+        if p["warm"]:
+            sol.set_option("true_warm_start", 1)
+        if p["precon"]:
+            sol.set_option("precon_mode", p["precon"])
         new = lambda n: torch.full((n,), float("nan"), dtype=torch.float64 if dt == np.float64 else torch.float32, device="cuda")
         its = None
         if p["entry"] == "device":
             d = sol.upload_system(s)
-            lam, dz = new(S * K), new(sol.N)
+            lam, dz = (sol.to_device(p["lam0"]) if p["warm"] else new(S * K)), new(sol.N)
             sol.linsys(*d, p["tol"], p["mi"], p["rho"], lam=lam, dz=dz)
         elif p["entry"] == "blocks":
             Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, 0.0, dt)                 # the block layouts, rho not yet added
@@ -113,7 +133,7 @@ def run_gpu(s, p, systems):
             Gd, Cd = sol.convert(*d[:6], p["rho"])
             Sb, Pb, gam, Gi = sol.form_schur(Gd, Cd, d[6], d[7])
             Pb = sol.form_ss(Sb, Pb)
-            lam, its = sol.pcg(Sb, Pb, gam, p["tol"], p["mi"])
+            lam, its = sol.pcg(Sb, Pb, gam, p["tol"], p["mi"], lam=sol.to_device(p["lam0"]) if p["warm"] else None)
             dz = sol.compute_dz(Gi, Cd, d[6], lam)
         else:
             d = sol.upload_batch(systems)
@@ -133,7 +153,8 @@ def run_gpu(s, p, systems):
 def case(rng, i, only=None):
     p = draw(rng, i)
     tag = f"case {i}: {p['S']}/{p['C']}/{p['K']} {np.dtype(p['dt']).name} {p['entry']}" + (f" x{p['B']}" if p["B"] > 1 else "") + \
-          f" tol {p['tol']:g} max_iters {p['mi']} rho {p['rho']:g} dense_q {int(p['dense_q'])} {p['opts']}"
+          f" tol {p['tol']:g} max_iters {p['mi']} rho {p['rho']:g} dense_q {int(p['dense_q'])} {p['opts']}" + \
+          (" warm start" if p["warm"] else "") + (f" precon_mode {p['precon']}" if p["precon"] else "")
     if only is not None and i not in only:
         return tag + " not run", True
     if not compiled(p["S"], p["C"]):
@@ -141,6 +162,8 @@ def case(rng, i, only=None):
     S, C, K, B = p["S"], p["C"], p["K"], p["B"]
     systems = [synth.make_system(S, C, K, seed=5000 + 16 * i + b, dense_q=p["dense_q"], rho=p["rho"]) for b in range(B)]
     s = systems[0]
+    if p["warm"]:
+        p["lam0"] = np.random.default_rng(9000 + i).standard_normal(S * K).astype(p["dt"])
     try:
         got = run_gpu(s, p, systems)
     except Exception as e:                                  # an option combination the library refuses: reported, not a failure
@@ -171,6 +194,8 @@ def case(rng, i, only=None):
                 bar_l, bar_d = max(bar_l, 16 * rel(lam_n, lam_o)), max(bar_d, 16 * rel(dz_n, dz_o))
             elif K <= 16:
                 bar_l, bar_d = 1e-4, 1e-3
+            if p["precon"] == 2:         # point-Jacobi: barely preconditioned CG loses conjugacy, hundreds of iterations amplify the
+                bar_l, bar_d = max(bar_l, 1e-5), max(bar_d, 1e-4)     # summation order (tests/test_oracle.py::test_fp32_point_jacobi_...)
             el, ed = rel(lam_b, lam_o), rel(dz_b, dz_o)
             if K == 1:
                 ed = 0.0                 # dz of a one-knot system is a difference of equal numbers: zero to rounding, no relative error
@@ -180,7 +205,7 @@ def case(rng, i, only=None):
             notes.append(f"sys {b}: lam {el:.1e} dz {ed:.1e} iters {it_b} (oracle {it_o})")
         else:
             (lam_o, dz_o, it_o), (lam_t, dz_t, it_t) = ref
-            f = F32_FACTOR if K > 16 else 8.0                  # a few knots: finite termination, order-chaotic (see the fp64 branch)
+            f = 16.0 if p["precon"] == 2 else F32_FACTOR if K > 16 else 8.0     # a few knots, point-Jacobi: order-chaotic (see the fp64 branch)
             bar_l = f * rel(lam_o, lam_t) + F32_FLOOR
             bar_d = f * rel(dz_o, dz_t) + F32_FLOOR
             el, ed = rel(lam_b, lam_t), rel(dz_b, dz_t)
