@@ -595,18 +595,32 @@ def linsys_solve_cluster(sysm, exit_tol, max_iters, dtype=np.float32, device=Non
     return lam, dz, iters, state
 
 
+MAX_CONSECUTIVE_TIMEOUTS = 3
+
+
 def linsys_solve_auto(sysm, exit_tol, max_iters, dtype=np.float32, device=None, group=None, state=None, variant=0):
     """The product entry for a knot-sharded solve: the in-kernel transport when it can be connected and its solves come
     back complete, else (every rank together) the RCCL all-gather schedule.  Returns (lambda, dz, iters, state);
-    state["transport"] says what ran; close_state(state) frees what it holds."""
+    state["transport"] says what the state runs on, state["last_transport"] what THIS solve ran on; close_state(state) frees what
+    it holds.  A cluster that has worked and then reports a hand-off time-out (a rank's launch came later than timeout_ms: a
+    stalled process, a busy GPU) is not given up at once: that solve is repeated over RCCL, the next one tries the cluster again -
+    its epochs only grow, a late launch leaves nothing a later one could take for its own - and only MAX_CONSECUTIVE_TIMEOUTS
+    time-outs in a row drop it for good."""
     if state is None or state.get("transport") == "xgmi":
         try:
             lam, dz, iters, st = linsys_solve_cluster(sysm, exit_tol, max_iters, dtype, device, group, state, variant=variant)
-            st["transport"] = "xgmi"
+            st["transport"] = st["last_transport"] = "xgmi"
+            st["timeouts"] = 0
             return lam, dz, iters, st
         except ClusterUnavailable as e:
-            close_state(state)                       # a connected cluster timed out later: drop it, keep going over RCCL
-            state = dict(transport="rccl", why=str(e)[:300])
+            again = (isinstance(e, ClusterTimeout) and state is not None and state.get("cl") is not None and
+                     state.get("timeouts", 0) + 1 < MAX_CONSECUTIVE_TIMEOUTS)
+            if again:                                # every rank alike: ClusterTimeout is raised on all of them together
+                state["timeouts"] = state.get("timeouts", 0) + 1
+                state["why"] = str(e)[:300]
+            else:
+                close_state(state)                   # never connected, or timed out too often: keep going over RCCL
+                state = dict(transport="rccl", why=str(e)[:300])
     # the RCCL schedule keeps its solver across calls (state["rccl_sol"]): a new one per call would run the calibration trials
     # again - but only for the shape, type and device it was made for
     sol = state.get("rccl_sol")
@@ -616,4 +630,5 @@ def linsys_solve_auto(sysm, exit_tol, max_iters, dtype=np.float32, device=None, 
         sol = state["rccl_sol"] = None
     lam, dz, iters, sol = linsys_solve_sharded(sysm, exit_tol, max_iters, dtype, device, group, sol=sol)
     state["rccl_sol"] = sol
+    state["last_transport"] = "rccl"
     return lam, dz, iters, state

@@ -457,3 +457,17 @@ def test_cluster_states_connected_and_closed_across_processes():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "FUZZ ok 0" in r.stdout and r.stdout.count("\nok   case") + r.stdout.startswith("ok   case") == 20, r.stdout[-3000:]
+
+
+def test_cluster_survives_a_late_rank():
+    """TWO PROCESSES through linsys_solve_auto: a rank that launches later than timeout_ms makes the hand-off time out on every
+    rank alike; that solve is repeated over the RCCL schedule (complete, equal to the oracle), the next solves run on the cluster
+    again (its epochs only grow: the late launch leaves nothing behind that a later one could take for its own), and only
+    MAX_CONSECUTIVE_TIMEOUTS in a row drop the cluster for good."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), OMP_NUM_THREADS="4",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], os.path.join(ROOT, "tests", "cluster_retry_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count(" ok") == 2, r.stdout[-2000:]
