@@ -2,7 +2,7 @@
 mirrors, one library call per rank and solve, one all-gather of the rows - is the one a multi-GPU node runs): shape, K, recurrence,
 exchange form, workgroup size; every case connects a fresh cluster state (linsys_solve_cluster), solves twice through it (the second
 time another system of the same shape, sometimes the other recurrence), closes it; now and then the automatic entry
-(linsys_solve_auto).  Every rank checks the gathered lambda / dz against the oracle's whole solve.  All ranks draw the same cases.
+(linsys_solve_auto).  At most 5 ranks on a 1-GPU box (the launcher counts towards its limit of 6 processes on the card).  Every rank checks the gathered lambda / dz against the oracle's whole solve.  All ranks draw the same cases.
       python -m torch.distributed.run --nnodes=1 --nproc-per-node R --master-addr 127.0.0.1 --master-port P tools/cluster_fuzz_ipc.py [cases] [seed]"""
 import os, sys
 import numpy as np
