@@ -189,6 +189,18 @@ def test_cluster_renews_its_epoch_space(variant, flat):
         assert np.array_equal(got, first), rep
         assert [c.rewinds for c in cl] == [0 if rep < 2 else 1] * R
     assert cl[0].launches_left(mi) > 5_000_000
+    # a rank's LEVEL-1 counter alone near its end (the solver also served plain multi-workgroup launches): it renews itself in
+    # stream order - its slots are written by the rank's own workgroups only - and no rank has to wait for another
+    for x in sols:
+        x.set_option("pcg_epoch", (top - 5) - (1 << 32))
+    for rep in range(3):
+        lam = torch.zeros(S * K, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        for r in range(R):
+            cl[r].pcg(dS, dP, dg, 0.0, mi, lam, its[r], stream=streams[r].cuda_stream)
+        torch.cuda.synchronize()
+        assert [int(i.cpu()[0]) for i in its] == [mi] * R and np.array_equal(lam.cpu().numpy(), first), rep
+    assert [c.rewinds for c in cl] == [1] * R
     # the C entry by itself: a launch that does not fit is refused
     for x in sols:
         x.set_option("cluster_epoch", top + 1 - (1 << 32))
