@@ -339,7 +339,10 @@ extern "C" int gato_solver_create(int S, int C, int K, int dtype, int device, ga
 
 extern "C" int gato_solver_create_batched(int S, int C, int K, int B, int dtype, int device, gato_solver **out)
 {
-    if (B < 1) { set_error("solver_create: batch must be >= 1"); return GATO_EINVAL; }
+    if (B < 1 || B > 65535) {           // the batched launches take one grid row (blockIdx.y) per system
+        set_error("solver_create: batch must be in 1 .. 65535 (got %d); split larger batches over several calls", B);
+        return GATO_EINVAL;
+    }
     if (!out || K < 1 || (dtype != GATO_F32 && dtype != GATO_F64)) {
         set_error("solver_create: bad arguments (K=%d dtype=%d)", K, dtype);
         return GATO_EINVAL;

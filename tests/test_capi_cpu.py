@@ -71,6 +71,15 @@ def test_short_input_lambda_rejected():
                                  P["g_val"], P["c_val"], [0.] * 3, 1, 1e-6, 10, False, 1e-3)
 
 
+@pytest.mark.parametrize("B", [0, -3, 65536, 1 << 20])
+def test_batch_size_outside_the_launch_grid_is_refused(B):
+    """One grid row per system: a batch beyond 65 535 systems (or below 1) is refused when the solver is created, with the reason
+    (checked before any device call: the same answer with and without a GPU)."""
+    h = ct.c_void_p()
+    rc = _lib.lib().gato_solver_create_batched(14, 7, 50, B, 0, 0, ct.byref(h))
+    assert rc == -1 and b"batch must be in 1 .. 65535" in _lib.lib().gato_last_error()
+
+
 def test_no_gpu_fails_loudly():
     """Without a GPU the product path must raise, never compute on the CPU."""
     import torch

@@ -1761,3 +1761,35 @@ def test_multi_workgroup_solve_beside_a_long_foreign_kernel(K):
     sol.close()
 
 
+
+
+def test_largest_batch_one_grid_row_per_system():
+    """65 535 systems in one call - the most a batch may hold (one grid row per system; more is refused when the solver is created,
+    tests/test_capi_cpu.py): IIWA 14/7/50 fp32, a shared matrix with the right-hand side of system b scaled by 1 + b / B.  The first,
+    middle and last systems against the oracle; every system against the first one scaled (the solve is linear in g and c)."""
+    from gato_python_amd.solver import Solver
+    S, C, K, B, dt = 14, 7, 50, 65535, np.float32
+    s = synth.make_system(S, C, K, seed=3)
+    sol = Solver(S, C, K, dt, batch=B)
+    i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int32)).cuda()
+    scale = (1.0 + np.arange(B) / B).astype(np.float32)
+    Gv = torch.from_numpy(np.tile(s.G_val.astype(dt), B)).cuda()
+    Cv = torch.from_numpy(np.tile(s.C_val.astype(dt), B)).cuda()
+    g = torch.from_numpy((scale[:, None] * s.g.astype(dt)[None, :]).reshape(-1)).cuda()
+    c = torch.from_numpy((scale[:, None] * s.c.astype(dt)[None, :]).reshape(-1)).cuda()
+    lam = torch.full((S * K * B,), float("nan"), dtype=torch.float32, device="cuda")
+    dz = torch.full((sol.N * B,), float("nan"), dtype=torch.float32, device="cuda")
+    its = torch.zeros(B, dtype=torch.int32, device="cuda")
+    sol.linsys_batched(i32(s.G_row), i32(s.G_col), Gv, i32(s.C_row), i32(s.C_col), Cv, g, c, 0.0, 25, s.rho, lam, dz, its)
+    torch.cuda.synchronize()
+    sol.check_status()
+    lam_h, dz_h = lam.cpu().numpy().reshape(B, -1), dz.cpu().numpy().reshape(B, -1)
+    assert np.isfinite(lam_h).all() and np.isfinite(dz_h).all()
+    assert int(its.min()) == 25 and int(its.max()) == 25
+    for b in (0, B // 2, B - 1):
+        lo, dzo, _ = co.linsys_solve(s.G_row, s.G_col, s.G_val, s.C_row, s.C_col, s.C_val, scale[b] * s.g.astype(dt), scale[b] * s.c.astype(dt),
+                                     S, C, K, 0.0, 25, s.rho, dtype=dt)
+        assert rel(lam_h[b], lo) < 1e-4 and rel(dz_h[b], dzo) < 1e-4, b
+    assert np.abs(lam_h / scale[:, None] - lam_h[0][None, :]).max() / np.abs(lam_h[0]).max() < 1e-4
+    assert np.abs(dz_h / scale[:, None] - dz_h[0][None, :]).max() / np.abs(dz_h[0]).max() < 1e-4
+    sol.close()
