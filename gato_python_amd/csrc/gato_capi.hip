@@ -1671,6 +1671,7 @@ extern "C" int gato_cluster_connect(gato_solver *s, const void *ipc_handles, voi
 extern "C" int gato_cluster_launches_left(gato_solver *s, int max_iters, long long *left)
 {
     if (!s->cl.on || !left) { set_error("cluster_launches_left: gato_cluster_connect first"); return GATO_EINVAL; }
+    if (max_iters < 0) { set_error("cluster_launches_left: max_iters must be >= 0 (got %d)", max_iters); return GATO_EINVAL; }
     const unsigned long long need = max_iters > 0x3FFFFFF0 ? 0x80000000ull : 2ull * (unsigned)max_iters + 8ull;
     const unsigned long long top = 0xFFFFFFFFull - need - 8ull;
     const unsigned long long used = s->cl.xepoch;          // (the level-1 counter of a rank renews itself in stream order: gato_cluster_pcg)
@@ -1761,6 +1762,7 @@ extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_P
         set_error("cluster_pcg: a cluster launch cannot be captured into a graph (its hand-off epochs are launch arguments)");
         return GATO_EINVAL;
     }
+    if (max_iters < 0) { set_error("cluster_pcg: max_iters must be >= 0 (got %d)", max_iters); return GATO_EINVAL; }
     int groups = 0, threads = 0, kpw = 0, cg1_total = 0, cg1_base = 0;
     const bool cg1 = cluster_plan_cg1(s, &groups, &threads, &kpw, &cg1_total, &cg1_base) != 0;
     const int fits = cg1 ? 1 : cluster_plan(s, &groups, &threads, &kpw);

@@ -210,6 +210,8 @@ def test_cluster_renews_its_epoch_space(variant, flat):
     p = lambda t: __import__("ctypes").c_void_p(t.data_ptr())
     rc = _lib.lib().gato_cluster_pcg(sols[0]._h, p(dS), p(dP), p(dg), p(lam), 0.0, mi, p(it), None)
     assert rc != 0 and b"epoch space" in _lib.lib().gato_last_error()
+    rc = _lib.lib().gato_cluster_pcg(sols[0]._h, p(dS), p(dP), p(dg), p(lam), 0.0, -1, p(it), None)      # -1 is what a time-out reports
+    assert rc != 0 and b"max_iters must be >= 0" in _lib.lib().gato_last_error()
     for c in cl:
         c.close()
     for x in sols:
