@@ -485,3 +485,48 @@ def test_cluster_survives_a_late_rank():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count(" ok") == 2, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("S,C", [(14, 7), (2, 1), (32, 16)])
+@pytest.mark.parametrize("R", [2, 3, 8])
+def test_sharded_whole_solve_with_one_knot_per_rank(S, C, R):
+    """The smallest shards: K = R (one knot per rank: its only block row is first AND last of the launch), R + 1, 2 R - 1 (ragged),
+    both recurrences asked for (the single-reduction one needs two knots per workgroup on every rank: all ranks take the default
+    together).  Whole sharded solves against the oracle's; systems this small run CG to its finite termination, where iterates
+    depend on the summation order at cond(S) * eps, so the bar is loose - a wrong halo or ghost block is an error of order one."""
+    from gato_python_amd.dist import ClusterPCG
+    from gato_python_amd.solver import Solver
+    for K in (R, R + 1, 2 * R - 1):
+        for variant in (0, 1):
+            s = synth.make_system(S, C, K, seed=K)
+            lam_w, dz_w, it_w = co.linsys_solve(*s.csr_args(), S, C, K, 1e-10, 100, s.rho, dtype=np.float64)
+            sols = [Solver(S, C, K, np.float64) for _ in range(R)]
+            for x in sols:
+                x.set_option("pcg_variant", variant)
+            cl = [ClusterPCG(x, r, R, inprocess_peers=True) for r, x in enumerate(sols)]
+            ClusterPCG.connect_inprocess(cl)
+            streams = lockstep_streams(R)
+            d = sols[0].upload_system(s)
+            lams = [torch.full((S * K,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(R)]
+            dzs = [torch.full((sols[0].N,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(R)]
+            its = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(R)]
+            torch.cuda.synchronize()
+            for r in range(R):
+                cl[r].linsys(d, 1e-10, 100, s.rho, lams[r], dzs[r], its[r], stream=streams[r].cuda_stream)
+            torch.cuda.synchronize()
+            n = S + C
+            la, da = np.empty(S * K), np.empty(sols[0].N)
+            for r in range(R):
+                k0, k1 = cl[r].k0, cl[r].k1
+                la[k0 * S:k1 * S] = lams[r][k0 * S:k1 * S].cpu().numpy()
+                hi = min(k1 * n, sols[0].N)
+                da[k0 * n:hi] = dzs[r][k0 * n:hi].cpu().numpy()
+            itg = [int(t.cpu()[0]) for t in its]
+            assert len(set(itg)) == 1 and abs(itg[0] - it_w) <= 2, (K, variant, itg, it_w)
+            assert np.abs(la - lam_w).max() / np.abs(lam_w).max() < 1e-5, (K, variant)
+            assert np.abs(da - dz_w).max() / max(np.abs(dz_w).max(), 1e-300) < 1e-4, (K, variant)
+            for c_ in cl:
+                c_.close()
+            for x in sols:
+                x.check_status()
+                x.close()
