@@ -1638,7 +1638,7 @@ def test_dz_in_the_fp32_two_row_epilogue_of_a_batch_is_bit_identical_to_the_dz_l
                 sol.close()
 
 
-def test_mixed_rows_kernel_every_size_it_serves():
+def test_mixed_rows_kernel_against_the_general_launch():
     """pcg_single_f64m_kernel (BASELINE configs[1]: four two-row waves + four waves of 16-lane DPP rows; round 2's dense layout it
     was A/B-ed against for two rounds is gone): every K it serves stops at the oracle's iteration with the oracle's solution, and
     the general launch (option no_pair) on the same matrices agrees to rounding (another grouping of the dot products)."""
