@@ -802,17 +802,13 @@ static int plan_cg1_k(gato_solver *s, int K, int *groups, int *threads, int *kpw
     int W = (K + per - 1) / per;
     if (s->pcg_groups > W) W = s->pcg_groups;
     if (W > max_wg) return 0;
-    // every workgroup needs two knots of its own (its two edge blocks on either side go to the neighbours): when the even split
-    // leaves the last workgroup ONE knot (K = 31 in workgroups of 6: 6 + 6 + 6 + 6 + 6 + 1), a workgroup more is tried (8 x 4 - 1)
-    for (int Wt = W; Wt <= max_wg; ++Wt) {
-        const int k_per = (K + Wt - 1) / Wt, Wn = (K + k_per - 1) / k_per;
-        if (Wn > 1 && k_per < 2) break;
-        if (Wn == 1 || K - (Wn - 1) * k_per >= 2) {
-            *groups = Wn; *threads = t; *kpw = k_per;
-            return 1;
-        }
-    }
-    return 0;
+    int k_per = (K + W - 1) / W;
+    W = (K + k_per - 1) / k_per;
+    // every workgroup needs two knots of its own (its two edge blocks on either side go to the neighbours).  When the even split
+    // leaves the last workgroup ONE knot, the launcher takes the balanced split instead (sizes k_per and k_per - 1: launch_pcg_cg1)
+    if (W > 1 && (k_per < 2 || (K - (W - 1) * k_per < 2 && k_per < 3))) return 0;
+    *groups = W; *threads = t; *kpw = k_per;
+    return 1;
 }
 
 // One-XCD launches (xcd_pack): the hand-off granules live in one place in memory and the eight XCDs are not equally far

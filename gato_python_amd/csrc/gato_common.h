@@ -168,6 +168,8 @@ struct PcgLaunch {
     int xcd_sel;                 // 0..7: the XCD (blockIdx % 8) that hosts them
     int wave_pub;                // launches of 2..32 workgroups: every wave publishes its own partial (no gather barrier); 0 = gathered form
     int knots_per_wg;            // contiguous knots owned by each workgroup (last may own fewer)
+    int split_extra;             // pcg_cg1 only, set by its launcher: > 0 = balanced split - the first split_extra workgroups own
+                                 // knots_per_wg knots, the others one less (the even split would leave the last workgroup ONE knot)
     int groups;                  // W = gridDim.x
     int threads;                 // blockDim.x (multiple of 64, >= knots_per_wg * S unless semi)
     int dpp_rows;                // 1: DPP-row layout (a knot owns whole 16-lane rows; threads >= knots_per_wg * 16 or 32), plain and cluster launches

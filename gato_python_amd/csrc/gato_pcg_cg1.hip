@@ -61,8 +61,9 @@ __global__ __launch_bounds__(MAXT) void pcg_cg1_kernel(PcgLaunch a)
     const int K = a.K;
     const int k_begin = MR ? a.k_begin : 0, k_end = MR ? a.k_end : K;       // this launch's knot range (a rank's shard)
     const int R = MR ? a.nranks : 1;
-    const int k0 = k_begin + wg * a.knots_per_wg;
-    const int nk = min(a.knots_per_wg, k_end - k0);
+    const int ex = a.split_extra;                                             // balanced split (see launch_pcg_cg1): sizes differ by one
+    const int k0 = k_begin + wg * a.knots_per_wg - (ex > 0 && wg > ex ? wg - ex : 0);
+    const int nk = ex > 0 ? (wg < ex ? a.knots_per_wg : a.knots_per_wg - 1) : min(a.knots_per_wg, k_end - k0);
     const int k1 = k0 + nk;
     const int jl = tid / S, r_ = tid - jl * S;        // lane knot slot (0 = knot k0-1), row
     const int k = k0 - 1 + jl;
@@ -504,9 +505,16 @@ int launch_pcg_cg1(const PcgLaunch &a0, hipStream_t st)
     const int lanes_needed = (a.knots_per_wg + 2) * S;
     // (every workgroup hands its first / last TWO blocks of w to its neighbours: two knots each, whenever the solve has neighbours)
     const bool neighbours = a.groups > 1 || (mr && a.nranks > 1);
+    // the even split (knots_per_wg each, the last workgroup the rest) unless that rest is a single knot: then the first split_extra
+    // workgroups take knots_per_wg, the others one less (31 knots in 6 workgroups: 6 + 5 + 5 + 5 + 5 + 5 instead of 5 x 6 + 1)
+    a.split_extra = 0;
+    if (neighbours && a.groups > 1 && a.knots_per_wg >= 3 && Kl - (a.groups - 1) * a.knots_per_wg == 1)
+        a.split_extra = Kl - a.groups * (a.knots_per_wg - 1);
+    const bool balanced = a.split_extra > 0;
     if (a.threads > MAXT || a.threads % 64 != 0 || a.threads < 4 * S || lanes_needed > a.threads || a.groups < 1 ||
         a.groups > 256 || (long long)a.groups * a.knots_per_wg < Kl || (long long)(a.groups - 1) * a.knots_per_wg >= Kl ||
-        (neighbours && (a.knots_per_wg < 2 || Kl - (a.groups - 1) * a.knots_per_wg < 2))) {
+        (balanced && (a.split_extra >= a.groups || a.split_extra * a.knots_per_wg + (a.groups - a.split_extra) * (a.knots_per_wg - 1) != Kl)) ||
+        (neighbours && !balanced && (a.knots_per_wg < 2 || Kl - (a.groups - 1) * a.knots_per_wg < 2))) {
         set_error("pcg_cg1: bad launch geometry (K=%d groups=%d knots/wg=%d threads=%d max=%d)", Kl, a.groups,
                   a.knots_per_wg, a.threads, MAXT);
         return GATO_EINVAL;

@@ -796,6 +796,34 @@ def test_single_reduction_variant(S, C, K, dt, opts):
     sol.close()
 
 
+@pytest.mark.parametrize("S,C,dt,threads,ks", [(32, 16, np.float64, 0, range(17, 130)), (14, 7, np.float64, 128, range(11, 100)),
+                                               (6, 3, np.float64, 64, range(9, 80))])
+def test_single_reduction_variant_every_k_of_a_range(S, C, dt, threads, ks):
+    """Every K of a range through the single-reduction kernel, several workgroups: the K whose even split would leave the last
+    workgroup a single knot (31, 37, ... 61 at 32/16 in workgroups of 6) run the BALANCED split (sizes differing by one) instead
+    of falling back to the default recurrence; each solve against the numpy restatement of the recurrence."""
+    balanced = 0
+    for K in ks:
+        s = synth.make_system(S, C, K, seed=500 + K)
+        Gd, Cd = co.convert(*s.csr_args()[:6], S, C, K, s.rho, dt)
+        Sb, Pb, gam, _ = co.form_schur(Gd, Cd, s.g, s.c, S, C, K)
+        Pb = co.form_ss(Sb, Pb, S, K)
+        lam_cg, it_cg = o.pcg_single_reduction(Sb, Pb, gam, S, K, 1e-9, 300)
+        sol = make_solver(S, C, K, dt)
+        sol.set_option("pcg_variant", 1)
+        if threads:
+            sol.set_option("pcg_threads", threads)
+        lam, it = sol.pcg(sol.to_device(Sb), sol.to_device(Pb), sol.to_device(gam), 1e-9, 300)
+        W, T = sol.get_option("last_groups"), sol.get_option("last_threads")
+        assert sol.get_option("last_variant") == 1, (K, W, T)
+        assert int(host(it)[0]) == it_cg and rel(host(lam), lam_cg) < 1e-8, (K, W, int(host(it)[0]), it_cg)
+        if W > 1:
+            kpw = -(-K // W)
+            balanced += K - (W - 1) * kpw == 1
+        sol.close()
+    assert balanced >= 3, balanced                          # the range does hold such K
+
+
 def test_extra_shape_library():
     """a shape added at build time (EXTRA_SHAPES) gets the GENERIC launch bounds - S = 16: the fp32 two-rows-per-lane
     kernel at 256 threads, i.e. FOUR waves under block sums that read eight waves' partials.  build() compiles a one-shape
