@@ -23,3 +23,18 @@ def test_random_solves_match_the_oracle():
         if not ok:
             bad.append(msg)
     assert ran >= 140 and not bad, "\n".join(bad)
+
+
+def test_random_csr_inputs_scatter_bit_for_bit():
+    """A fixed-seed slice of tools/csr_fuzz.py: CSR rows shuffled, thinned, with explicit zeros, repeated columns, columns outside
+    the block structure, empty rows and empty matrices - the gather kernel, the stage path and the fused assembly launch of a
+    whole solve must leave G_dense / C_dense bit for bit as the restatements of csr_to_custom_G / _C do."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import csr_fuzz
+    rng = np.random.default_rng(1)
+    bad = []
+    for i in range(80):
+        msg, ok = csr_fuzz.case(rng, i)
+        if not ok:
+            bad.append(msg)
+    assert not bad, "\n".join(bad)
