@@ -38,3 +38,14 @@ def test_random_csr_inputs_scatter_bit_for_bit():
         if not ok:
             bad.append(msg)
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("args", [("14", "7", "f64", "700"), ("14", "7", "f32", "1500"), ("32", "16", "f32", "300", "pcg_variant=1")])
+def test_both_sides_of_the_planner_boundaries(args):
+    """tools/boundary_sweep.py on a short range: the K at which the planner changes the launch (workgroup size of the one-workgroup
+    kernels, one -> several workgroups, row layout ...) are located and a whole solve is held against the oracle at K = b - 1, b,
+    b + 1 of each.  The long ranges (to K = 140 000, the semi-resident forms, the ring, streaming) are run by hand:
+    profiles/r05_boundary_sweep.txt."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "boundary_sweep.py"), *args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "BOUNDARIES ok 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
