@@ -201,6 +201,9 @@ struct gato_solver {
 namespace {
 struct InFlight { hipEvent_t ev; int cus; hipStream_t st; int device; };
 std::mutex g_gate_mu;
+// held from the admission check over the launch to the record of its event: two host threads must not both find the chip free and
+// both launch (round 5: four threads with a solver and a stream each ran into hand-off time-outs - check, then act, was not atomic)
+std::mutex g_launch_mu;
 std::vector<InFlight> g_inflight;
 std::vector<InFlight> g_free_events;      // recycled events, kept with the device they were created on
 
@@ -854,9 +857,12 @@ static int calibrate_xcd(gato_solver *s, const PcgLaunch &a0, bool cg1, hipStrea
             if (++s->pcg_launch_id <= 0) s->pcg_launch_id = 1;
             t.launch_id = s->pcg_launch_id;
             int rc;
-            if ((rc = gate_before(s->device, s->num_cus, s->num_cus, st))) return rc;
-            rc = cg1 ? s->ops->pcg_cg1(t, st) : s->ops->pcg_resident(t, st);
-            if (rc == GATO_OK) rc = gate_after(s->device, s->num_cus, st);
+            {
+                std::lock_guard<std::mutex> launch_lock(g_launch_mu);
+                if ((rc = gate_before(s->device, s->num_cus, s->num_cus, st))) return rc;
+                rc = cg1 ? s->ops->pcg_cg1(t, st) : s->ops->pcg_resident(t, st);
+                if (rc == GATO_OK) rc = gate_after(s->device, s->num_cus, st);
+            }
             if (rc) return rc;
             GATO_HIP_CHECK(hipEventSynchronize(s->ev_cal1));
             float ms = 0.f;
@@ -1007,6 +1013,8 @@ static int pcg_one(gato_solver *s, const void *d_S, const void *d_Pinv, const vo
         }
         if (s->tuning) return GATO_OK;                                       // nothing to measure for this geometry
         const bool gate = gated && !capturing;      // (a captured multi-workgroup launch was refused above; the gate records events)
+        std::unique_lock<std::mutex> launch_lock(g_launch_mu, std::defer_lock);
+        if (gate) launch_lock.lock();
         if (gate && (rc = gate_before(s->device, s->num_cus, need_cus, st))) return rc;
         rc = cg1 ? s->ops->pcg_cg1(a, st) : a.semi == 3 ? s->ops->pcg_dma(a, st) : s->ops->pcg_resident(a, st);
         if (rc == GATO_OK && gate) rc = gate_after(s->device, need_cus, st);
@@ -1836,6 +1844,7 @@ extern "C" int gato_cluster_pcg(gato_solver *s, const void *d_S, const void *d_P
     // the launches of a cluster wait for EACH OTHER: they are never queued behind one another (ranks sharing a device
     // exist in tests only), but they count for the other launches of this process
     int rc;
+    std::lock_guard<std::mutex> launch_lock(g_launch_mu);
     if ((rc = cg1 ? s->ops->pcg_cg1(a, st) : a.semi == 3 ? s->ops->pcg_dma(a, st) : s->ops->pcg_resident(a, st))) return rc;
     return gate_after(s->device, groups, st);
 }

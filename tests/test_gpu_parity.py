@@ -1821,3 +1821,62 @@ def test_largest_batch_one_grid_row_per_system():
     assert np.abs(lam_h / scale[:, None] - lam_h[0][None, :]).max() / np.abs(lam_h[0]).max() < 1e-4
     assert np.abs(dz_h / scale[:, None] - dz_h[0][None, :]).max() / np.abs(dz_h[0]).max() < 1e-4
     sol.close()
+
+
+def test_solvers_driven_from_four_host_threads():
+    """Four host threads, each with a solver and a stream of its own, 150 whole solves each (multi-workgroup persistent launches:
+    four of them do not fit the chip together, so the co-residency gate - process-wide state under a mutex - makes launches wait for
+    each other), plus a fifth thread calling the reference surface (its cached solver, another mutex).  Every result equal to the
+    thread's first one bit for bit and to the oracle; no time-out, no dead-lock."""
+    import threading
+    from gato_python_amd import linsys as host_entry
+    S, C, dt = 14, 7, np.float32
+    Ks = [4096, 3000, 4096, 700]
+    sysms = [system(S, C, K, seed=60 + i) for i, K in enumerate(Ks)]
+    answers = [co.linsys_solve(*s.csr_args(), S, C, s.K, 0.0, 25, s.rho, dtype=dt) for s in sysms]
+    errors = []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            s, K = sysms[i], Ks[i]
+            sol = make_solver(S, C, K, dt)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                dev = sol.upload_system(s)
+                lam, dz = sol.new(S * K), sol.new(sol.N)
+                first = None
+                for n in range(150):
+                    sol.linsys(*dev, 0.0, 25, s.rho, lam, dz)
+                    if n % 50 == 0 or n == 149:
+                        st.synchronize()
+                        got = (host(lam).copy(), host(dz).copy())
+                        first = got if first is None else first
+                        assert np.array_equal(got[0], first[0]) and np.array_equal(got[1], first[1]), (i, n)
+                st.synchronize()
+                sol.check_status()
+            assert rel(first[0], answers[i][0]) < 2e-3 and rel(first[1], answers[i][1]) < 2e-3, i
+            sol.close()
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((i, repr(e)[:300]))
+
+    def surface():
+        try:
+            P = synth.PENDULUM
+            want = None
+            for n in range(150):
+                lam, dz = host_entry.linsys_solve(P["G_row"], P["G_col"], P["G_val"], P["C_row"], P["C_col"], P["C_val"], P["g_val"], P["c_val"],
+                                                  P["input_lambda"], 1, 1e-6, 10, False, 1e-3)
+                want = lam if want is None else want
+                assert lam == want
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(("surface", repr(e)[:300]))
+
+    os.environ["GATO_VERBOSE"] = "0"
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)] + [threading.Thread(target=surface)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a thread is stuck"
+    assert not errors, errors
