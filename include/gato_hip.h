@@ -46,6 +46,10 @@ extern "C" {
 #define GATO_PRECON_BLOCK_JACOBI 1 /* SS_PRECON 0: main blocks -theta^-1 only */
 #define GATO_PRECON_POINT_JACOBI 2 /* both 0: diag(1 / S.main_ii) */
 
+/* Threads: a gato_solver is used by one host thread at a time (its plan, counters and work buffers are per solver); different
+ * solvers may be driven from different threads and streams concurrently - the process-wide state (the admission of persistent
+ * multi-workgroup launches to the chip, the cached solver of gato_linsys_solve_*, the mirror pool) is locked, gato_last_error is
+ * per thread. */
 typedef struct gato_solver gato_solver;
 
 /* ---- library / device ------------------------------------------------------------------- */
